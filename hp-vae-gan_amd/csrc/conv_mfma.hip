@@ -1,0 +1,383 @@
+// 3x3 / 3x3x3 "same" convolution as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// Replaces (reference, /root/reference): nn.Conv3d / nn.Conv2d forward as used by
+//   ConvBlock3D       modules/networks_3d.py:48-56     ConvBlock2D   modules/networks_2d.py:53-61
+//   ConvBlock3DSN     modules/networks_3d.py:59-70     ConvBlock2DSN modules/networks_2d.py:64-75
+//   tails             modules/networks_3d.py:175,341,362
+// and, through a flipped/transposed weight pack, their backward-data pass (stride 1, pad 1:
+// bwd-data is a forward conv with W'[c][o][tap] = W[o][c][ntaps-1-tap]).
+//
+// GEMM view (per batch sample b and output time-plane t):
+//     Y[o][q] = sum_{tap} sum_{c} W[o][c][tap] * X[c][q + off(tap)]
+//   M = output channels (32 per MFMA tile, MB tiles per wave)
+//   N = output positions q of one (Th x Tw) spatial tile, flattened with the LDS row stride
+//       RS = Tw + 2 so that every tap is a constant offset (the two halo columns per row yield
+//       junk columns of the GEMM that are never stored)
+//   K = (tap, input-channel) - two input channels per v_mfma_f32_32x32x2_f32.
+//
+// Data movement: the input tile (CC channels x KT time planes x (Th+2) x (Tw+2), zero padded) is
+// staged through LDS one channel chunk at a time (register staged, so the producer's
+// BatchNorm-apply + LeakyReLU can be fused into the load); the B operand is read with
+// conflict-free ds_read_b32 (32 consecutive dwords per half wave).  The A operand (weights) is
+// pre-packed in fragment order and read straight from L2 with one 16-byte load per lane per
+// (tap, m-tile); all workgroups read the same 442 KB so it stays L2 resident.
+// Accumulation is exact fp32 (v_mfma_f32_32x32x2_f32 == chain of fmaf).
+#include "hpvg_common.h"
+
+namespace {
+
+struct ConvFwdArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* in_scale;
+  const float* in_shift;
+  float* y;
+  int B, Cin, Cout, T, H, W;
+  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, ntiles, mbtot, nj;
+  int in_lrelu, out_lrelu;
+};
+
+template <int CP> struct AVecT;
+template <> struct AVecT<4> { typedef f32x4 type; };
+template <> struct AVecT<2> { typedef f32x2 type; };
+
+constexpr int NJMAX = 4;  // (Th+2)*RS <= 1024
+
+template <int CC, int KT, int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) {
+  constexpr int CP = CC / 2;
+  constexpr int TAPS = KT * 9;
+  typedef typename AVecT<CP>::type AVec;
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tile = hpvg_xcd_remap(blockIdx.x, a.ntiles);
+  const int tw_i = tile % a.ntw;
+  int r = tile / a.ntw;
+  const int th_i = r % a.nth;
+  r /= a.nth;
+  const int t = r % a.T;
+  const int b = r / a.T;
+  const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
+  const int mb0 = blockIdx.y * MB;
+  const long HW = (long)a.H * a.W;
+  const int RS = a.RS, PL = a.PL;
+
+  // ---- per-thread staging slots: position p = j*256+tid inside one (Th+2) x RS input plane
+  int gofs[NJMAX];
+  unsigned okmask = 0, wmask = 0;
+  const int plload = (a.Th + 2) * RS;
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) {
+    const int p = j * 256 + tid;
+    gofs[j] = 0;
+    if (j < a.nj && p < plload) {
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      wmask |= 1u << j;
+      if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+        okmask |= 1u << j;
+        gofs[j] = gh * a.W + gw;
+      }
+    }
+  }
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][i][e] = 0.f;
+
+  const bool prologue = a.in_scale != nullptr;
+  const float* xl = xs + half * KT * PL + l31 + wave * 32;
+
+  for (int ch = 0; ch < a.nchunk; ++ch) {
+    if (ch > 0) __syncthreads();
+    // ---------------- stage CC x KT planes into LDS (zero padded, optional affine+lrelu)
+#pragma unroll 2
+    for (int c = 0; c < CC; ++c) {
+      const int cg = ch * CC + c;
+      const bool cok = cg < a.Cin;
+      float sc = 1.f, sh = 0.f;
+      if (prologue && cok) {
+        sc = a.in_scale[cg];
+        sh = a.in_shift[cg];
+      }
+      float v[KT][NJMAX];
+#pragma unroll
+      for (int dt = 0; dt < KT; ++dt) {
+        const int tt = t + dt - (KT == 3 ? 1 : 0);
+        const bool tok = cok && tt >= 0 && tt < a.T;
+        const float* src = a.x + (((long)b * a.Cin + (cok ? cg : 0)) * a.T + (tok ? tt : 0)) * HW;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j) {
+          const bool ld = tok && ((okmask >> j) & 1u);
+          v[dt][j] = ld ? src[gofs[j]] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < KT; ++dt) {
+        const int tt = t + dt - (KT == 3 ? 1 : 0);
+        const bool tok = cok && tt >= 0 && tt < a.T;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j) {
+          if ((wmask >> j) & 1u) {
+            float val = v[dt][j];
+            if (prologue && tok && ((okmask >> j) & 1u)) {
+              val = val * sc + sh;
+              if (a.in_lrelu) val = hpvg_lrelu(val);
+            }
+            xs[(c * KT + dt) * PL + j * 256 + tid] = val;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------- MFMA over (tap, channel pair)
+    const AVec* wpt = reinterpret_cast<const AVec*>(a.wp) + ((long)(ch * TAPS) * a.mbtot + mb0) * 64 + lane;
+    AVec av[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) av[m] = wpt[m * 64];
+#pragma unroll 1
+    for (int dt = 0; dt < KT; ++dt) {
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          // prefetch the next tap's A fragments (the pack has one tap of tail padding)
+          wpt += (long)a.mbtot * 64;
+          AVec an[MB];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
+          const float* xt = xl + dt * PL + dh * RS + dw;
+#pragma unroll
+          for (int cp = 0; cp < CP; ++cp) {
+            float bv[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bv[i] = xt[(2 * cp * KT) * PL + i * 128];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+                acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[i], acc[m][i], 0, 0, 0);
+          }
+#pragma unroll
+          for (int m = 0; m < MB; ++m) av[m] = an[m];
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue: bias, optional LeakyReLU, masked store
+  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int blk = wave + 4 * i;
+    const int q = blk * 32 + l31;
+    const int hh = q / RS, ww = q - hh * RS;
+    const int gh = h0 + hh, gw = w0 + ww;
+    const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
+    if (!ok) continue;
+    const long sp = (long)t * HW + (long)gh * a.W + gw;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (co < a.Cout) {
+          float val = acc[m][i][e];
+          if (a.bias) val += a.bias[co];
+          if (a.out_lrelu) val = hpvg_lrelu(val);
+          a.y[((long)b * a.Cout + co) * a.T * HW + sp] = val;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight pack: natural [Cout][Cin][taps] -> MFMA A-fragment order
+//   wp[chunk][tap][mblock][lane][cp] = Wsrc[o = mblock*32 + (lane&31)][c = chunk*CC + 2cp + (lane>>5)][tap]
+// transpose_flip=1 packs the backward-data weights (Wsrc[o'][c'][tap] = W[c'][o'][ntaps-1-tap]).
+// A device scalar `inv_scale` (1/sigma of spectral norm) is folded in when given.
+__global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, float* __restrict__ wp,
+                                 int Cin_k, int Cout_k, int taps, int CC, int nchunk, int mbtot, int transpose_flip,
+                                 long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CP = CC / 2;
+  long r = idx;
+  const int cp = r % CP; r /= CP;
+  const int lane = r % 64; r /= 64;
+  const int mb = r % mbtot; r /= mbtot;
+  const int tap = r % taps; r /= taps;
+  const int ch = (int)r;
+  float val = 0.f;
+  if (ch < nchunk) {  // else: tail padding (one extra tap block) stays zero
+    const int o = mb * 32 + (lane & 31);
+    const int c = ch * CC + 2 * cp + (lane >> 5);
+    if (o < Cout_k && c < Cin_k) {
+      if (!transpose_flip) val = w[((long)o * Cin_k + c) * taps + tap];
+      else val = w[((long)c * Cout_k + o) * taps + (taps - 1 - tap)];
+      if (inv_scale) val *= inv_scale[0];
+    }
+  }
+  wp[idx] = val;
+}
+
+inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
+
+struct Plan {
+  int Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, nj;
+  size_t lds;
+};
+
+// Tile planner: minimise (waves of workgroups over the chip) x (per-workgroup MFMA rounds).
+Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  const int CC = conv_cc(Cin);
+  const int mbtot = hpvg_cdiv(Cout, 32);
+  Plan best{};
+  double best_cost = 1e300;
+  for (int MB = (mbtot >= 2 ? 2 : 1); MB >= 1; --MB) {
+    const int gridy = hpvg_cdiv(mbtot, MB);
+    for (int Tw = 1; Tw <= W; ++Tw) {
+      const int ntw = hpvg_cdiv(W, Tw);
+      if (Tw != hpvg_cdiv(W, ntw)) continue;  // only balanced splits of W
+      const int RS = Tw + 2;
+      for (int Th = 1; Th <= H; ++Th) {
+        const int nth = hpvg_cdiv(H, Th);
+        if (Th != hpvg_cdiv(H, nth)) continue;
+        const int qmax = (Th - 1) * RS + Tw - 1;
+        const int nblocks = qmax / 32 + 1;
+        if (nblocks > 16) break;
+        if ((Th + 2) * RS > NJMAX * 256) break;
+        const int rounds = hpvg_cdiv(nblocks, 4);
+        const int NB = rounds <= 1 ? 1 : (rounds == 2 ? 2 : 4);
+        int PL = (Th + 2) * RS;
+        const int need = 128 * NB + 2 * RS + 2;
+        if (PL < need) PL = need;
+        const size_t lds = (size_t)CC * KT * PL * sizeof(float);
+        if (lds > 160 * 1024) continue;
+        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+        const long nwg = (long)B * T * nth * ntw * gridy;
+        const long slots = (long)HPVG_NUM_CU * per_cu;
+        const double waves = nwg <= slots ? 1.0 : (double)nwg / (double)slots;
+        // per-WG time ~ MFMA rounds (scaled by m-tiles) + fixed staging/sync overhead
+        const double per = (double)NB * MB + 0.6 + 0.002 * (Th + 2) * RS;
+        const double cost = waves * per;
+        if (cost < best_cost - 1e-9) {
+          best_cost = cost;
+          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds};
+        }
+      }
+    }
+  }
+  return best;
+}
+
+template <int CC, int KT, int MB, int NB>
+int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_kernel<CC, KT, MB, NB>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles, p.gridy), dim3(256), p.lds, s, a);
+  return hpvg_launch_status();
+}
+
+template <int CC, int KT>
+int dispatch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
+  if (p.MB == 2) {
+    switch (p.NB) {
+      case 1: return launch_conv<CC, KT, 2, 1>(a, p, s);
+      case 2: return launch_conv<CC, KT, 2, 2>(a, p, s);
+      default: return launch_conv<CC, KT, 2, 4>(a, p, s);
+    }
+  }
+  switch (p.NB) {
+    case 1: return launch_conv<CC, KT, 1, 1>(a, p, s);
+    case 2: return launch_conv<CC, KT, 1, 2>(a, p, s);
+    default: return launch_conv<CC, KT, 1, 4>(a, p, s);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// number of floats of the packed-weight buffer for a conv with Cin -> Cout (kernel view)
+size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) {
+  const int CC = conv_cc(Cin);
+  const int nchunk = hpvg_cdiv(Cin, CC);
+  const int mbtot = hpvg_cdiv(Cout, 32);
+  const size_t per_tap = (size_t)mbtot * 64 * (CC / 2);
+  return ((size_t)nchunk * KT * 9 + 1) * per_tap;  // +1 tap of zero tail padding (prefetch)
+}
+
+// w: natural layout of the LAYER weight [Cout_layer][Cin_layer][KT][3][3].
+// transpose_flip = 0: pack for the forward conv (kernel Cin=Cin_layer, Cout=Cout_layer)
+// transpose_flip = 1: pack for backward-data (kernel Cin=Cout_layer, Cout=Cin_layer)
+int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                              int transpose_flip, void* stream) {
+  if (!w || !wp || (KT != 1 && KT != 3) || Cin_layer < 1 || Cout_layer < 1) return HPVG_ERR_ARG;
+  const int Cin_k = transpose_flip ? Cout_layer : Cin_layer;
+  const int Cout_k = transpose_flip ? Cin_layer : Cout_layer;
+  const int CC = conv_cc(Cin_k);
+  const int nchunk = hpvg_cdiv(Cin_k, CC);
+  const int mbtot = hpvg_cdiv(Cout_k, 32);
+  const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
+                     Cin_k, Cout_k, KT * 9, CC, nchunk, mbtot, transpose_flip, total);
+  return hpvg_launch_status();
+}
+
+// y[b][o][t][h][w] = bias[o] + sum_{c,tap} Wp[o][c][tap] * f(x)[b][c][t+dt-pt][h+dh-1][w+dw-1]
+// f = identity, or (in_scale[c]*x + in_shift[c]) followed by LeakyReLU(0.2) when in_lrelu (zero padding
+// is applied AFTER f, as in the reference where f is the previous block's BatchNorm+LeakyReLU output).
+int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
+                      int in_lrelu, float* y, int out_lrelu, int B, int Cin, int Cout, int T, int H, int W, int KT,
+                      void* stream) {
+  if (!x || !wp || !y) return HPVG_ERR_ARG;
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
+  if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT);
+  if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  ConvFwdArgs a;
+  a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
+  a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.nth = p.nth; a.ntw = p.ntw; a.nblocks = p.nblocks;
+  const int CC = conv_cc(Cin);
+  a.nchunk = hpvg_cdiv(Cin, CC);
+  a.ntiles = B * T * p.nth * p.ntw;
+  a.mbtot = hpvg_cdiv(Cout, 32);
+  a.nj = p.nj;
+  a.in_lrelu = in_lrelu; a.out_lrelu = out_lrelu;
+  hipStream_t s = (hipStream_t)stream;
+  if (CC == 8) return KT == 3 ? dispatch_conv<8, 3>(a, p, s) : dispatch_conv<8, 1>(a, p, s);
+  return KT == 3 ? dispatch_conv<4, 3>(a, p, s) : dispatch_conv<4, 1>(a, p, s);
+}
+
+// Debug/introspection: the tile plan the launcher will use (for tests and DESIGN.md tables).
+// out[0..9] = Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds_bytes, ntiles
+int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT);
+  out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
+  out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
+  return HPVG_OK;
+}
+
+}  // extern "C"

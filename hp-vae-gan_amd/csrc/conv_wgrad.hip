@@ -1,0 +1,295 @@
+// Convolution backward-weight (and bias gradient) for the 3x3 / 3x3x3 "same" convs, on the
+// gfx950 fp32 matrix cores.
+//
+// Replaces (reference): the weight-gradient half of aten::convolution_backward reached from
+//   total_loss.backward() / errD_total.backward()      train_video.py:182,200  train_image.py:193,215
+// and, in the gradient-penalty double backward (modules/utils.py:14-18), the derivative of a
+// backward-data conv with respect to its weight (same contraction, operands swapped by the caller).
+//
+//   dW[o][c][dt][dh][dw] = sum_{b,t,h,w} dY[b][o][t][h][w] * f(X)[b][c][t+dt-pt][h+dh-1][w+dw-1]
+//
+// GEMM view per (dt): M = o (32 per tile), N = c (32 per tile), K = output positions, two per
+// v_mfma_f32_32x32x2_f32.  A workgroup owns one dt, one 64x64 (o,c) block (one 32x32 sub-block per
+// wave, 9 in-plane taps -> 9 accumulator tiles = 144 VGPRs) and walks a strided list of spatial
+// tiles, keeping the accumulators in registers; it writes ONE partial slab at the end, and a second
+// kernel sums the slabs in a fixed order (bitwise reproducible - no float atomics).
+// The dY tile and the halo'd X tile of one time plane are staged in LDS with odd row strides so
+// that the 32 lanes of a half wave (32 different channels, same position) hit 32 different banks.
+#include "hpvg_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const float* dy;
+  const float* x;
+  const float* in_scale;
+  const float* in_shift;
+  float* part;
+  int B, Cin, Cout, T, H, W;
+  int Th, Tw, RS, DS, XS, QK, nth, ntw, ntiles, S, ncb, nob;
+  int in_lrelu;
+};
+
+template <int KT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dys = lds;                 // [64][DS]
+  float* xsm = lds + 64 * a.DS;     // [64][XS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int oblk = wave >> 1, cblk = wave & 1;
+  const int dt = blockIdx.y;
+  const int z = blockIdx.z;
+  const int ob = z / a.ncb, cb = z % a.ncb;
+  const int RS = a.RS, DS = a.DS, XS = a.XS;
+  const long HW = (long)a.H * a.W;
+  const bool active = (ob * 64 + oblk * 32 < a.Cout) && (cb * 64 + cblk * 32 < a.Cin);
+  const bool prologue = a.in_scale != nullptr;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+    const int tw_i = tile % a.ntw;
+    int r = tile / a.ntw;
+    const int th_i = r % a.nth;
+    r /= a.nth;
+    const int t = r % a.T;
+    const int b = r / a.T;
+    const int tt = t + dt - (KT == 3 ? 1 : 0);
+    if (tt < 0 || tt >= a.T) continue;  // uniform: this time tap falls into the zero padding
+    const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
+
+    // ---- per-thread slots (2 each for dY and X planes)
+    int dofs[2], xofs[2];
+    unsigned dok = 0, dwr = 0, xok = 0, xwr = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 256 + tid;
+      dofs[j] = 0; xofs[j] = 0;
+      if (p < DS) {
+        dwr |= 1u << j;
+        const int hh = p / RS, ww = p - hh * RS;
+        const int gh = h0 + hh, gw = w0 + ww;
+        if (hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W) { dok |= 1u << j; dofs[j] = gh * a.W + gw; }
+      }
+      if (p < XS) {
+        xwr |= 1u << j;
+        const int hh = p / RS, ww = p - hh * RS;
+        const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+        if (hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) { xok |= 1u << j; xofs[j] = gh * a.W + gw; }
+      }
+    }
+
+    __syncthreads();  // previous tile's MFMA reads are done
+    const float* dyb = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
+    const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + tt) * HW;
+    const long cstride = (long)a.T * HW;
+#pragma unroll 4
+    for (int c = 0; c < 64; ++c) {
+      const bool ook = ob * 64 + c < a.Cout;
+      const bool cok = cb * 64 + c < a.Cin;
+      float sc = 1.f, sh = 0.f;
+      if (prologue && cok) { sc = a.in_scale[cb * 64 + c]; sh = a.in_shift[cb * 64 + c]; }
+      float dv[2], xv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        dv[j] = (ook && ((dok >> j) & 1u)) ? dyb[c * cstride + dofs[j]] : 0.f;
+        xv[j] = (cok && ((xok >> j) & 1u)) ? xb[c * cstride + xofs[j]] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if ((dwr >> j) & 1u) dys[c * DS + j * 256 + tid] = dv[j];
+        if ((xwr >> j) & 1u) {
+          float val = xv[j];
+          if (prologue && cok && ((xok >> j) & 1u)) {
+            val = val * sc + sh;
+            if (a.in_lrelu) val = hpvg_lrelu(val);
+          }
+          xsm[c * XS + j * 256 + tid] = val;
+        }
+      }
+    }
+    __syncthreads();
+
+    if (active) {
+      const float* dl = dys + (oblk * 32 + l31) * DS + half;
+      const float* xl = xsm + (cblk * 32 + l31) * XS + half;
+      for (int q0 = 0; q0 < a.QK; q0 += 2) {
+        const float av = dl[q0];
+        float bv[9];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) bv[dh * 3 + dw] = xl[q0 + dh * RS + dw];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial slab: part[s][dt][z][tap9][o64][c64]
+  float* pp = a.part + ((((long)blockIdx.x * KT + dt) * gridDim.z + z) * 9) * 4096;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = oblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      pp[(long)k * 4096 + row * 64 + cblk * 32 + l31] = active ? acc[k][e] : 0.f;
+    }
+}
+
+// dW[o][c][dt][tap9] = sum_s part[s][dt][z][tap9][o%64][c%64]; one thread per slab element, fixed order.
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int KT, int nob,
+                                         int ncb, int Cout, int Cin, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_s = (long)KT * nob * ncb * 9 * 4096;
+  if (idx >= per_s) return;
+  long r = idx;
+  const int c64 = r % 64; r /= 64;
+  const int o64 = r % 64; r /= 64;
+  const int tap = r % 9; r /= 9;
+  const int z = r % (nob * ncb); r /= (nob * ncb);
+  const int dt = (int)r;
+  const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 64 + c64;
+  if (o >= Cout || c >= Cin) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    s0 += part[(long)(s + 0) * per_s + idx];
+    s1 += part[(long)(s + 1) * per_s + idx];
+    s2 += part[(long)(s + 2) * per_s + idx];
+    s3 += part[(long)(s + 3) * per_s + idx];
+  }
+  for (; s < S; ++s) s0 += part[(long)s * per_s + idx];
+  const float tot = (s0 + s1) + (s2 + s3);
+  float* dst = dw + (((long)o * Cin + c) * KT + dt) * 9 + tap;
+  *dst = accumulate ? *dst + tot : tot;
+}
+
+// per-channel sum over (b, spatial): out[c] = sum_b sum_s x[b][c][s]   (bias gradient)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                                                           long S) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* p = x + ((long)b * C + c) * S;
+    float loc = 0.f;
+    int cnt = 0;
+    for (long i = threadIdx.x; i < S; i += 256) {
+      loc += p[i];
+      if (++cnt == 64) { acc += loc; loc = 0.f; cnt = 0; }
+    }
+    acc += loc;
+  }
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) out[c] = (float)tot;
+}
+
+struct WPlan {
+  int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb;
+  size_t lds;
+};
+
+WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  WPlan best{};
+  double best_cost = 1e300;
+  const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
+  for (int Tw = 1; Tw <= W; ++Tw) {
+    const int ntw = hpvg_cdiv(W, Tw);
+    if (Tw != hpvg_cdiv(W, ntw)) continue;
+    const int RS = Tw + 2;
+    for (int Th = 1; Th <= H; ++Th) {
+      const int nth = hpvg_cdiv(H, Th);
+      if (Th != hpvg_cdiv(H, nth)) continue;
+      const int QK = (Th * RS + 1) & ~1;
+      const int DS = (QK + 1) | 1;               // >= QK+1, odd
+      const int XS = ((Th + 2) * RS + 4) | 1;    // reads reach QK-1+1 + 2*RS+2 <= (Th+2)*RS + 3
+      if (DS > 512 || XS > 512) break;
+      const size_t lds = (size_t)64 * (DS + XS) * sizeof(float);
+      if (lds > 78 * 1024) break;
+      const long ntiles = (long)B * T * nth * ntw;
+      // useful fraction of the K loop and per-tile fixed cost (staging + two barriers)
+      const double work = (double)ntiles * (QK * 0.5 * 9.0 + 60.0);
+      if (work < best_cost) {
+        best_cost = work;
+        best = WPlan{Th, Tw, RS, DS, XS, QK, nth, ntw, 0, nob, ncb, lds};
+      }
+    }
+  }
+  if (best.Th) {
+    const long ntiles = (long)B * T * best.nth * best.ntw;
+    long cap = (2L * HPVG_NUM_CU) / ((long)KT * nob * ncb);
+    if (cap < 1) cap = 1;
+    best.S = (int)(ntiles < cap ? ntiles : cap);
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
+  return (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+}
+
+// dw: natural layout [Cout][Cin][KT][3][3]; accumulate != 0 adds into dw instead of overwriting.
+int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_scale, const float* in_shift, int in_lrelu,
+                             float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
+                             int W, int KT, void* stream) {
+  if (!dy || !x || !dw || !ws) return HPVG_ERR_ARG;
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
+  if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
+  const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
+  if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  const size_t need = (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+  if (ws_bytes < need) return HPVG_ERR_WORKSPACE;
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.part = (float*)ws;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
+  a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
+  a.ntiles = B * T * p.nth * p.ntw; a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr3 = false, attr1 = false;
+  const dim3 grid(p.S, KT, p.nob * p.ncb);
+  if (KT == 3) {
+    if (!attr3) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); attr3 = true; }
+    hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), p.lds, s, a);
+  } else {
+    if (!attr1) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); attr1 = true; }
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), p.lds, s, a);
+  }
+  int st = hpvg_launch_status();
+  if (st != HPVG_OK) return st;
+  const long per_s = (long)KT * p.nob * p.ncb * 9 * 4096;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(hpvg_cdiv(per_s, 256)), dim3(256), 0, s, (const float*)ws, dw, p.S, KT,
+                     p.nob, p.ncb, Cout, Cin, accumulate);
+  return hpvg_launch_status();
+}
+
+// out[c] = sum over batch and all spatial positions of x[b][c][...]  (conv bias gradient)
+int hpvg_channel_sum_f32(const float* x, float* out, int B, int C, long S, void* stream) {
+  if (!x || !out || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, S);
+  return hpvg_launch_status();
+}
+
+int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
+  out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.QK; out[5] = p.S; out[6] = p.DS; out[7] = p.XS;
+  out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
+  return HPVG_OK;
+}
+
+}  // extern "C"

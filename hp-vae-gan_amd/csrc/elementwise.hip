@@ -1,0 +1,731 @@
+// HBM-bound elementwise / reduction kernels of the HP-VAE-GAN train step (gfx950, wave64).
+// Each kernel cites the reference statement it replaces (paths relative to /root/reference).
+// Layout: activations are NCDHW / NCHW contiguous fp32; S = T*H*W (or H*W) is the per-channel extent.
+// Reductions accumulate short fp32 runs per thread, then combine in fp64 in a fixed order
+// (two-stage: per-block partials -> one finishing block), so results are run-to-run identical.
+#include "hpvg_common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS_MAX = 1024;
+
+__device__ __forceinline__ float ld(const float* p, long i) { return p[i]; }
+
+// ------------------------------------------------------------------ generic scalar reductions
+enum RedOp { RED_SUM = 0, RED_SQ = 1, RED_SQDIFF = 2, RED_KL = 3 };
+
+template <int OP>
+__device__ __forceinline__ float red_term(const float* a, const float* b, long i) {
+  if (OP == RED_SUM) return a[i];
+  if (OP == RED_SQ) { const float v = a[i]; return v * v; }
+  if (OP == RED_SQDIFF) { const float d = a[i] - b[i]; return d * d; }
+  // RED_KL: -0.5*(1 + logvar - mu^2 - exp(logvar)), a = mu, b = logvar   (modules/losses.py:8)
+  const float mu = a[i], lv = b[i];
+  return -0.5f * (1.f + lv - mu * mu - expf(lv));
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                              double* __restrict__ part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  float loc = 0.f;
+  int cnt = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    loc += red_term<OP>(a, b, i);
+    if (++cnt == 32) { acc += loc; loc = 0.f; cnt = 0; }
+  }
+  acc += loc;
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// out[0] = scale * sum(part[0..np))   (single block)
+__global__ __launch_bounds__(256) void reduce_finish_kernel(const double* __restrict__ part, int np, double scale,
+                                                             float* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) acc += part[i];
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) out[0] = (float)(tot * scale);
+}
+
+template <int OP>
+int reduce_scalar(const float* a, const float* b, long n, double scale, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!a || !out || !ws || n < 1) return HPVG_ERR_ARG;
+  int nb = hpvg_cdiv(n, 256 * 16);
+  if (nb > RED_BLOCKS_MAX) nb = RED_BLOCKS_MAX;
+  if (nb < 1) nb = 1;
+  if (ws_bytes < (size_t)nb * sizeof(double)) return HPVG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(reduce_partial_kernel<OP>, dim3(nb), dim3(256), 0, s, a, b, n, (double*)ws);
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, scale, out);
+  return hpvg_launch_status();
+}
+
+// ------------------------------------------------------------------ BatchNorm (train mode)
+// per-channel (sum, sumsq) partials: grid (nsplit, C)
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int B, int C, long S, int nsplit,
+                                                                double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y, k = blockIdx.x;
+  const long chunk = (S + nsplit - 1) / nsplit;
+  const long lo = (long)k * chunk, hi = (lo + chunk < S) ? lo + chunk : S;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* p = x + ((long)b * C + c) * S;
+    float s1 = 0.f, s2 = 0.f;
+    int cnt = 0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+      const float v = p[i];
+      s1 += v;
+      s2 += v * v;
+      if (++cnt == 32) { a1 += s1; a2 += s2; s1 = 0.f; s2 = 0.f; cnt = 0; }
+    }
+    a1 += s1;
+    a2 += s2;
+  }
+  const double t1 = hpvg_block_sum_d(a1, sh);
+  const double t2 = hpvg_block_sum_d(a2, sh);
+  if (threadIdx.x == 0) {
+    part[((long)c * nsplit + k) * 2 + 0] = t1;
+    part[((long)c * nsplit + k) * 2 + 1] = t2;
+  }
+}
+
+// mean / biased var -> invstd, fused affine (scale, shift), running-stat update (unbiased var, momentum)
+// reference: nn.BatchNorm3d in ConvBlock3D, modules/networks_3d.py:54 (train mode on every forward)
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nsplit, int C, double count, float eps, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                   float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += part[((long)c * nsplit + k) * 2 + 0];
+    s2 += part[((long)c * nsplit + k) * 2 + 1];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const float sc = g * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = bt - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// y = lrelu?(scale[c]*x + shift[c])      grid (blocks over S, B*C)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ y, int C, long S,
+                                                          int lrelu) {
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const float sc = scale[c], sh = shift[c];
+  const float* xp = x + (long)bc * S;
+  float* yp = y + (long)bc * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    float v = xp[i] * sc + sh;
+    if (lrelu) v = hpvg_lrelu(v);
+    yp[i] = v;
+  }
+}
+
+// BN+LeakyReLU backward, reduction pass: per channel  s1 = sum dz, s2 = sum dz*xhat
+//   z = scale*r + shift, dz = dh * (z > 0 ? 1 : 0.2), xhat = (r - mean)*invstd
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* __restrict__ dh, const float* __restrict__ r,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   int B, int C, long S, int nsplit, int lrelu,
+                                                                   double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y, k = blockIdx.x;
+  const long chunk = (S + nsplit - 1) / nsplit;
+  const long lo = (long)k * chunk, hi = (lo + chunk < S) ? lo + chunk : S;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* dp = dh + ((long)b * C + c) * S;
+    const float* rp = r + ((long)b * C + c) * S;
+    float s1 = 0.f, s2 = 0.f;
+    int cnt = 0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+      const float rv = rp[i];
+      float dz = dp[i];
+      if (lrelu && !(rv * sc + sf > 0.f)) dz *= HPVG_LRELU_SLOPE;
+      s1 += dz;
+      s2 += dz * ((rv - mu) * is);
+      if (++cnt == 32) { a1 += s1; a2 += s2; s1 = 0.f; s2 = 0.f; cnt = 0; }
+    }
+    a1 += s1;
+    a2 += s2;
+  }
+  const double t1 = hpvg_block_sum_d(a1, sh);
+  const double t2 = hpvg_block_sum_d(a2, sh);
+  if (threadIdx.x == 0) {
+    part[((long)c * nsplit + k) * 2 + 0] = t1;
+    part[((long)c * nsplit + k) * 2 + 1] = t2;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsplit, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += part[((long)c * nsplit + k) * 2 + 0];
+    s2 += part[((long)c * nsplit + k) * 2 + 1];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  sums[2 * c] = (float)s1;
+  sums[2 * c + 1] = (float)s2;
+}
+
+// dr = gamma*invstd * (dz - s1/N - xhat*s2/N)
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ r,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ sums, float* __restrict__ dr, int C,
+                                                                  long S, float inv_count, int lrelu) {
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  const float m1 = sums[2 * c] * inv_count, m2 = sums[2 * c + 1] * inv_count;
+  const float* dp = dh + (long)bc * S;
+  const float* rp = r + (long)bc * S;
+  float* op = dr + (long)bc * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    const float rv = rp[i];
+    float dz = dp[i];
+    if (lrelu && !(rv * sc + sf > 0.f)) dz *= HPVG_LRELU_SLOPE;
+    const float xh = (rv - mu) * is;
+    op[i] = sc * (dz - m1 - xh * m2);
+  }
+}
+
+// ------------------------------------------------------------------ pointwise
+// out = dy * (h > 0 ? 1 : 0.2)    (leaky_relu_backward on the in-place activated tensor)
+__global__ __launch_bounds__(256) void lrelu_mask_mul_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                              float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = h[i] > 0.f ? dy[i] : HPVG_LRELU_SLOPE * dy[i];
+}
+
+// y = tanh(x + res)   (res optional)   networks_3d.py:377,404
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = x[i];
+    if (res) v += res[i];
+    y[i] = tanhf(v);
+  }
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float t = y[i];
+    dx[i] = dy[i] * (1.f - t * t);
+  }
+}
+
+// z = eps*exp(0.5*logvar) + mu   networks_3d.py:31-33
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, float* __restrict__ z, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    z[i] = eps[i] * expf(0.5f * lv[i]) + mu[i];
+}
+// dlogvar = dz * eps * 0.5*exp(0.5*logvar)   (dmu = dz)
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, float* __restrict__ dlv, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]);
+}
+// KL backward: dmu = g*mu/n ; dlogvar = g*(-0.5)*(1-exp(lv))/n
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mu,
+                                                      const float* __restrict__ lv, float* __restrict__ dmu,
+                                                      float* __restrict__ dlv, long n) {
+  const float gs = g[0] / (float)n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    dmu[i] = gs * mu[i];
+    dlv[i] = gs * (-0.5f) * (1.f - expf(lv[i]));
+  }
+}
+// MSE backward: da = g*2*(a-b)/n
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                       const float* __restrict__ b, float* __restrict__ da, long n) {
+  const float gs = 2.f * g[0] / (float)n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) da[i] = gs * (a[i] - b[i]);
+}
+// out[i] = g[0]*coef
+__global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restrict__ g, float coef, float* __restrict__ out,
+                                                           long n) {
+  const float v = g[0] * coef;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v;
+}
+// out = x / s[0]   (spectral norm: weight = weight_orig / sigma)
+__global__ __launch_bounds__(256) void div_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                          float* __restrict__ out, long n) {
+  const float d = s[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] / d;
+}
+// out = alpha*a + (1-alpha)*b, alpha a device scalar    modules/utils.py:9
+__global__ __launch_bounds__(256) void lerp_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ alpha, float* __restrict__ out, long n) {
+  const float al = alpha[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = al * a[i] + (1.f - al) * b[i];
+}
+
+// ------------------------------------------------------------------ gradient penalty   modules/utils.py:18
+// per (b, voxel): nrm = ||g[b,:,s]||_2 over C channels; partial sum of (nrm-1)^2
+__global__ __launch_bounds__(256) void gp_partial_kernel(const float* __restrict__ g, int B, int C, long S,
+                                                          double* __restrict__ part) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const long n = (long)B * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / S, s = i - b * S;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = g[((long)b * C + c) * S + s];
+      ss += v * v;
+    }
+    const float d = sqrtf(ss) - 1.f;
+    acc += (double)(d * d);
+  }
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// dg[b,c,s] = gout * lambda/(B*S) * 2*(nrm-1)/nrm * g[b,c,s]      (0 where nrm == 0)
+__global__ __launch_bounds__(256) void gp_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ g,
+                                                      float* __restrict__ dg, int B, int C, long S, float lambda) {
+  const long n = (long)B * S;
+  const float k = gout[0] * lambda * 2.f / (float)n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / S, s = i - b * S;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = g[((long)b * C + c) * S + s];
+      ss += v * v;
+    }
+    const float nrm = sqrtf(ss);
+    const float f = nrm > 0.f ? k * (nrm - 1.f) / nrm : 0.f;
+    for (int c = 0; c < C; ++c) {
+      const long o = ((long)b * C + c) * S + s;
+      dg[o] = f * g[o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tri/bi-linear resize, align_corners=True
+// utils/images.py:13,17,24 (F.interpolate(..., align_corners=True)).  src = dst*(in-1)/(out-1) in fp32.
+struct Lin { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lin lin_coef(int o, int in, float scale) {
+  const float src = scale * (float)o;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  const float w1 = src - (float)i0;
+  return Lin{i0, i1, 1.f - w1, w1};
+}
+
+// y[bc][to][ho][wo]; optional fused noise injection: yn = y + amp*noise   (networks_3d.py:399-400)
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ noise, float amp, float* __restrict__ yn,
+                                                            long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo, float st,
+                                                            float sh, float sw) {
+  const long n = BC * To * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho; r /= Ho;
+    const int to = r % To; r /= To;
+    const float* xp = x + r * ((long)Ti * Hi * Wi);
+    const Lin lt = lin_coef(to, Ti, st), lh = lin_coef(ho, Hi, sh), lw = lin_coef(wo, Wi, sw);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ti = a ? lt.i1 : lt.i0;
+      const float wt = a ? lt.w1 : lt.w0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int hi = b ? lh.i1 : lh.i0;
+        const float wh = b ? lh.w1 : lh.w0;
+        const float* row = xp + ((long)ti * Hi + hi) * Wi;
+        acc += wt * wh * (lw.w0 * row[lw.i0] + lw.w1 * row[lw.i1]);
+      }
+    }
+    y[i] = acc;
+    if (yn) yn[i] = acc + amp * noise[i];
+  }
+}
+// dx (pre-zeroed) += scatter of dy
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long BC, int Ti,
+                                                            int Hi, int Wi, int To, int Ho, int Wo, float st, float sh, float sw) {
+  const long n = BC * To * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho; r /= Ho;
+    const int to = r % To; r /= To;
+    float* xp = dx + r * ((long)Ti * Hi * Wi);
+    const Lin lt = lin_coef(to, Ti, st), lh = lin_coef(ho, Hi, sh), lw = lin_coef(wo, Wi, sw);
+    const float g = dy[i];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ti = a ? lt.i1 : lt.i0;
+      const float wt = a ? lt.w1 : lt.w0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int hi = b ? lh.i1 : lh.i0;
+        const float wh = b ? lh.w1 : lh.w0;
+        float* row = xp + ((long)ti * Hi + hi) * Wi;
+        const float w = g * wt * wh;
+        if (w * lw.w0 != 0.f) atomicAdd(row + lw.i0, w * lw.w0);
+        if (w * lw.w1 != 0.f) atomicAdd(row + lw.i1, w * lw.w1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ spectral norm (torch hook semantics, 1 power iteration)
+// networks_3d.py:63 nn.utils.spectral_norm: v <- normalize(W^T u), u <- normalize(W v), sigma = u^T W v
+// single workgroup of 1024 threads; W is [Co][K] row-major (K = Cin*taps).
+__device__ __forceinline__ double block1024_sum(double v, double* sh) {
+  v = hpvg_wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ w, float* __restrict__ u,
+                                                              float* __restrict__ v, float* __restrict__ sigma_out,
+                                                              float* __restrict__ inv_sigma_out, int Co, int K, int do_iter,
+                                                              float eps, float* __restrict__ wv_ws) {
+  __shared__ double sh[16];
+  __shared__ float su[1024];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int o = tid; o < Co; o += 1024) su[o] = u[o];
+  __syncthreads();
+  if (do_iter) {
+    // v = normalize(W^T u)
+    double nrm = 0.0;
+    for (int k = tid; k < K; k += 1024) {
+      float acc = 0.f;
+      for (int o = 0; o < Co; ++o) acc += w[(long)o * K + k] * su[o];
+      v[k] = acc;
+      nrm += (double)acc * acc;
+    }
+    const double tot = block1024_sum(nrm, sh);
+    const float den = fmaxf((float)sqrt(tot), eps);
+    __syncthreads();
+    for (int k = tid; k < K; k += 1024) v[k] = v[k] / den;
+    __syncthreads();
+  }
+  // wv = W v  (one wave per row, rows strided by 16)
+  for (int o = wave; o < Co; o += 16) {
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += w[(long)o * K + k] * v[k];
+    acc = hpvg_wave_sum(acc);
+    if (lane == 0) wv_ws[o] = acc;
+  }
+  __syncthreads();
+  if (do_iter) {
+    double nrm = 0.0;
+    for (int o = tid; o < Co; o += 1024) nrm += (double)wv_ws[o] * wv_ws[o];
+    const double tot = block1024_sum(nrm, sh);
+    const float den = fmaxf((float)sqrt(tot), eps);
+    for (int o = tid; o < Co; o += 1024) {
+      const float un = wv_ws[o] / den;
+      su[o] = un;
+      u[o] = un;
+    }
+    __syncthreads();
+  }
+  double sg = 0.0;
+  for (int o = tid; o < Co; o += 1024) sg += (double)su[o] * wv_ws[o];
+  const double sig = block1024_sum(sg, sh);
+  if (tid == 0) {
+    sigma_out[0] = (float)sig;
+    inv_sigma_out[0] = (float)(1.0 / sig);
+  }
+}
+
+// dW_orig = (dW_eff - (sum(dW_eff*W_orig)/sigma^2) * sigma * u v^T / sigma ... ) see DESIGN: W_eff = W/sigma
+//   dW_orig[o][k] = (dW_eff[o][k] - (s/sigma) * u[o] v[k]) / sigma,   s = sum dW_eff .* W_orig / sigma
+__global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ dweff, const float* __restrict__ worig,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ sigma, float* __restrict__ dworig, int Co,
+                                                       int K) {
+  __shared__ double sh[16];
+  const long n = (long)Co * K;
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) acc += (double)dweff[i] * worig[i];
+  const double dot = block1024_sum(acc, sh);
+  const float sg = sigma[0];
+  const float coef = (float)(dot / ((double)sg * sg));  // = sum(dW_eff .* W_eff) / sigma
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const int o = (int)(i / K), k = (int)(i - (long)o * K);
+    dworig[i] = (dweff[i] - coef * u[o] * v[k]) / sg;
+  }
+}
+
+// ------------------------------------------------------------------ optimizer   train_video.py:88,201-202
+// g *= min(1, max_norm/(sqrt(sqsum)+1e-6))   torch.nn.utils.clip_grad_norm_
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ sqsum,
+                                                          float max_norm, float* __restrict__ coef_out) {
+  const float total = sqrtf(sqsum[0]);
+  float coef = max_norm / (total + 1e-6f);
+  if (coef > 1.f) coef = 1.f;
+  if (coef_out && blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = coef; coef_out[1] = total; }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] *= coef;
+}
+// torch.optim.Adam (amsgrad=False, weight_decay=0)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                                    float bc1, float bc2_sqrt) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+inline int ew_blocks(long n) {
+  long nb = (n + 256 * 4 - 1) / (256 * 4);
+  if (nb < 1) nb = 1;
+  if (nb > 4096) nb = 4096;
+  return (int)nb;
+}
+inline int bn_nsplit(int B, int C, long S) {
+  // enough blocks to fill the chip (>= ~1024) but at least ~2048 elements per block
+  long want = (1024 + C - 1) / C;
+  long maxs = (S * B + 2047) / 2048;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  return (int)want;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hpvg_reduce_ws_bytes() { return (size_t)RED_BLOCKS_MAX * sizeof(double); }
+size_t hpvg_bn_ws_bytes(int C) { return (size_t)C * 64 * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float); }
+
+// mean / invstd / (scale, shift) of BatchNorm in train mode + running-stat update
+int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* ws,
+                            size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!x || !mean || !invstd || !scale || !shift || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)B * (double)S,
+                     eps, momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+  return hpvg_launch_status();
+}
+
+int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int lrelu, int B, int C, long S,
+                        void* stream) {
+  if (!x || !scale || !shift || !y || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  int nbx = hpvg_cdiv(S, 256 * 4);
+  if (nbx > 1024) nbx = 1024;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(nbx, B * C), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, C, S, lrelu);
+  return hpvg_launch_status();
+}
+
+// dr, dgamma, dbeta of  h = lrelu?(BN_train(r))  given dh
+int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B,
+                        int C, long S, void* stream) {
+  if (!dh || !r || !mean || !invstd || !scale || !shift || !dr || !dgamma || !dbeta || !ws) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  double* part = (double*)ws;
+  float* sums = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
+  hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns,
+                     lrelu, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
+                     sums);
+  int nbx = hpvg_cdiv(S, 256 * 4);
+  if (nbx > 1024) nbx = 1024;
+  hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
+                     (const float*)sums, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
+  return hpvg_launch_status();
+}
+
+int hpvg_lrelu_mask_mul_f32(const float* dy, const float* h, float* out, long n, void* stream) {
+  if (!dy || !h || !out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(lrelu_mask_mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, h, out, n);
+  return hpvg_launch_status();
+}
+
+int hpvg_tanh_fwd_f32(const float* x, const float* res, float* y, long n, void* stream) {
+  if (!x || !y || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, res, y, n);
+  return hpvg_launch_status();
+}
+int hpvg_tanh_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream) {
+  if (!dy || !y || !dx || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+  return hpvg_launch_status();
+}
+
+int hpvg_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream) {
+  if (!mu || !logvar || !eps || !z || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
+  return hpvg_launch_status();
+}
+int hpvg_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream) {
+  if (!dz || !logvar || !eps || !dlogvar || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, logvar, eps, dlogvar, n);
+  return hpvg_launch_status();
+}
+
+// out[0] = mean(-0.5*(1 + logvar - mu^2 - exp(logvar)))   modules/losses.py:7-9
+int hpvg_kl_fwd_f32(const float* mu, const float* logvar, float* out, void* ws, size_t ws_bytes, long n, void* stream) {
+  return reduce_scalar<RED_KL>(mu, logvar, n, 1.0 / (double)n, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int hpvg_kl_bwd_f32(const float* gout, const float* mu, const float* logvar, float* dmu, float* dlogvar, long n, void* stream) {
+  if (!gout || !mu || !logvar || !dmu || !dlogvar || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gout, mu, logvar, dmu, dlogvar, n);
+  return hpvg_launch_status();
+}
+// out[0] = mean((a-b)^2)   nn.MSELoss, train_video.py:355
+int hpvg_mse_fwd_f32(const float* a, const float* b, float* out, void* ws, size_t ws_bytes, long n, void* stream) {
+  if (!b) return HPVG_ERR_ARG;
+  return reduce_scalar<RED_SQDIFF>(a, b, n, 1.0 / (double)n, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int hpvg_mse_bwd_f32(const float* gout, const float* a, const float* b, float* da, long n, void* stream) {
+  if (!gout || !a || !b || !da || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gout, a, b, da, n);
+  return hpvg_launch_status();
+}
+// out[0] = scale * sum(x)     (scale = +-1/n for the WGAN terms, train_video.py:170,178,194)
+int hpvg_sum_scaled_f32(const float* x, float* out, double scale, void* ws, size_t ws_bytes, long n, void* stream) {
+  return reduce_scalar<RED_SUM>(x, nullptr, n, scale, out, ws, ws_bytes, (hipStream_t)stream);
+}
+// out[0] = sum(x^2)
+int hpvg_sqsum_f32(const float* x, float* out, void* ws, size_t ws_bytes, long n, void* stream) {
+  return reduce_scalar<RED_SQ>(x, nullptr, n, 1.0, out, ws, ws_bytes, (hipStream_t)stream);
+}
+// out[i] = gout[0]*coef
+int hpvg_fill_scaled_f32(const float* gout, float coef, float* out, long n, void* stream) {
+  if (!gout || !out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(fill_scaled_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gout, coef, out, n);
+  return hpvg_launch_status();
+}
+// out = x / s[0]   (s: device scalar)
+int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream) {
+  if (!x || !s || !out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(div_scalar_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, s, out, n);
+  return hpvg_launch_status();
+}
+// out = alpha*a + (1-alpha)*b   (alpha: device scalar)
+int hpvg_lerp_f32(const float* a, const float* b, const float* alpha, float* out, long n, void* stream) {
+  if (!a || !b || !alpha || !out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(lerp_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n);
+  return hpvg_launch_status();
+}
+
+// out[0] = lambda * mean_{b,s} (||g[b,:,s]||_2 - 1)^2
+int hpvg_gp_fwd_f32(const float* g, float* out, float lambda, void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!g || !out || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  const long n = (long)B * S;
+  int nb = hpvg_cdiv(n, 256 * 8);
+  if (nb > RED_BLOCKS_MAX) nb = RED_BLOCKS_MAX;
+  if (ws_bytes < (size_t)nb * sizeof(double)) return HPVG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gp_partial_kernel, dim3(nb), dim3(256), 0, s, g, B, C, S, (double*)ws);
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, (double)lambda / (double)n, out);
+  return hpvg_launch_status();
+}
+int hpvg_gp_bwd_f32(const float* gout, const float* g, float* dg, float lambda, int B, int C, long S, void* stream) {
+  if (!gout || !g || !dg || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(gp_bwd_kernel, dim3(ew_blocks((long)B * S)), dim3(256), 0, (hipStream_t)stream, gout, g, dg, B, C, S,
+                     lambda);
+  return hpvg_launch_status();
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+// y = resize(x) to (To,Ho,Wo), align_corners=True; if noise: yn = y + amp*noise
+int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, float amp, float* yn, long BC, int Ti, int Hi,
+                                int Wi, int To, int Ho, int Wo, void* stream) {
+  if (!x || !y || BC < 1 || Ti < 1 || Hi < 1 || Wi < 1 || To < 1 || Ho < 1 || Wo < 1) return HPVG_ERR_ARG;
+  if ((noise == nullptr) != (yn == nullptr)) return HPVG_ERR_ARG;
+  const long n = BC * To * Ho * Wo;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, noise, amp, yn, BC, Ti,
+                     Hi, Wi, To, Ho, Wo, ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  return hpvg_launch_status();
+}
+int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
+                                    void* stream) {
+  if (!dy || !dx || BC < 1) return HPVG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dx, 0, (size_t)BC * Ti * Hi * Wi * sizeof(float), s) != hipSuccess) return HPVG_ERR_LAUNCH;
+  const long n = BC * To * Ho * Wo;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, BC, Ti, Hi, Wi, To, Ho, Wo,
+                     ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  return hpvg_launch_status();
+}
+
+// spectral norm: optional power iteration (updates u, v in place), sigma and 1/sigma (device scalars)
+// ws: Co floats
+int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, int Co, int K, int do_iter,
+                           float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (!w || !u || !v || !sigma || !inv_sigma || !ws || Co < 1 || Co > 1024 || K < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < (size_t)Co * sizeof(float)) return HPVG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(sn_power_iter_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, u, v, sigma, inv_sigma, Co, K, do_iter,
+                     eps, (float*)ws);
+  return hpvg_launch_status();
+}
+int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
+                    int Co, int K, void* stream) {
+  if (!dweff || !worig || !u || !v || !sigma || !dworig || Co < 1 || K < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dweff, worig, u, v, sigma, dworig, Co, K);
+  return hpvg_launch_status();
+}
+
+// g *= min(1, max_norm/(sqrt(sqsum[0]) + 1e-6)); coef_out (optional, 2 floats) = {coef, total_norm}
+int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, float* coef_out, void* stream) {
+  if (!g || !sqsum || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqsum, max_norm, coef_out);
+  return hpvg_launch_status();
+}
+// one Adam step over a flat range; step >= 1 is the 1-based step count
+int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                       int step, void* stream) {
+  if (!p || !g || !m || !v || n < 1 || step < 1) return HPVG_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     (float)bc1, (float)sqrt(bc2));
+  return hpvg_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""Dimension-generic building blocks behind modules/networks_3d.py and modules/networks_2d.py.
+
+Same module tree, child names, parameter/buffer names and registration order as the reference classes, so
+state_dicts are interchangeable with the reference's; every forward runs on the gfx950
+kernels through ops.*.  Parameters are created with the same torch initialisers, in the same order, as
+nn.ConvNd.reset_parameters / nn.utils.spectral_norm / nn.BatchNormNd, so a seeded construction consumes the CPU
+generator exactly like the reference does."""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from .. import ops
+from .. import utils as hp_utils
+
+
+def _kernel_shape(dims):
+    return (3,) * dims
+
+
+class Conv(nn.Module):
+    """nn.Conv3d / nn.Conv2d(k=3, s=1, p=1) with bias (reference: networks_3d.py:51,175,341)."""
+
+    def __init__(self, dims, in_channel, out_channel, ker_size=3, padding=1, stride=1):
+        super().__init__()
+        if ker_size != 3 or padding != 1 or stride != 1:
+            raise NotImplementedError("the MI355X path implements ker_size=3, padding=1, stride=1 (reference defaults)")
+        self.dims = dims
+        self.weight = nn.Parameter(torch.empty(out_channel, in_channel, *_kernel_shape(dims)))
+        self.bias = nn.Parameter(torch.empty(out_channel))
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        fan_in = in_channel * 3 ** dims
+        bound = 1 / math.sqrt(fan_in)
+        init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, act=False):
+        return ops.Conv.apply(x, self.weight, self.bias, act)
+
+
+class SNConv(nn.Module):
+    """nn.utils.spectral_norm(nn.ConvNd(k=3, p=1)) (reference: networks_3d.py:63): parameters `bias`, `weight_orig`,
+    buffers `weight_u`, `weight_v`; one power iteration per training-mode forward, eps 1e-12."""
+
+    def __init__(self, dims, in_channel, out_channel, ker_size=3, padding=1, stride=1):
+        super().__init__()
+        if ker_size != 3 or padding != 1 or stride != 1:
+            raise NotImplementedError("the MI355X path implements ker_size=3, padding=1, stride=1 (reference defaults)")
+        self.dims = dims
+        weight = torch.empty(out_channel, in_channel, *_kernel_shape(dims))
+        init.kaiming_uniform_(weight, a=math.sqrt(5))
+        bias = torch.empty(out_channel)
+        fan_in = in_channel * 3 ** dims
+        bound = 1 / math.sqrt(fan_in)
+        init.uniform_(bias, -bound, bound)
+        self.bias = nn.Parameter(bias)
+        self.weight_orig = nn.Parameter(weight)
+        h, w = out_channel, weight.numel() // out_channel
+        u = torch.nn.functional.normalize(weight.new_empty(h).normal_(0, 1), dim=0, eps=1e-12)
+        v = torch.nn.functional.normalize(weight.new_empty(w).normal_(0, 1), dim=0, eps=1e-12)
+        self.register_buffer('weight_u', u)
+        self.register_buffer('weight_v', v)
+
+    def effective_weight(self):
+        return ops.SpectralNormWeight.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, 1e-12)
+
+    def forward(self, x, act=False):
+        return ops.Conv.apply(x, self.effective_weight(), self.bias, act)
+
+
+class BatchNorm(nn.Module):
+    """nn.BatchNorm3d / 2d parameters and buffers (eps 1e-5, momentum 0.1, affine, track_running_stats)."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.eps = 1e-5
+        self.momentum = 0.1
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, r, lrelu=True):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+            return ops.BNAct.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
+                                   lrelu)
+        with torch.no_grad():
+            scale = self.weight / torch.sqrt(self.running_var + self.eps)
+            shift = self.bias - self.running_mean * scale
+        return ops.AffineAct.apply(r, scale, shift, lrelu)
+
+
+class ConvBlock(nn.Module):
+    """Conv -> BatchNorm (batch statistics) -> LeakyReLU(0.2) (reference ConvBlock3D/2D: networks_3d.py:48-56).
+    bn=False / act=None give the plain conv used for the encoder's mu / logvar heads (networks_3d.py:99-100)."""
+
+    def __init__(self, dims, in_channel, out_channel, ker_size, padding, stride, bn=True, act='lrelu'):
+        super().__init__()
+        if act not in ('lrelu', None):
+            raise NotImplementedError("only LeakyReLU(0.2) ('lrelu') is implemented on the MI355X path")
+        self.conv = Conv(dims, in_channel, out_channel, ker_size, padding, stride)
+        if bn:
+            self.norm = BatchNorm(out_channel)
+        self.has_bn = bn
+        self.act = act
+
+    def forward(self, x):
+        if self.has_bn:
+            return self.norm(self.conv(x), lrelu=self.act is not None)
+        return self.conv(x, act=self.act is not None)
+
+
+class ConvBlockSN(nn.Module):
+    """spectral_norm(Conv) -> LeakyReLU(0.2); NO BatchNorm (reference ConvBlock3DSN/2DSN: networks_3d.py:59-70;
+    its `bn` flag selects spectral norm).  The bn=False reflect-padding branch is dead code in the reference."""
+
+    def __init__(self, dims, in_channel, out_channel, ker_size, padding, stride, bn=True, act='lrelu'):
+        super().__init__()
+        if not bn:
+            raise NotImplementedError("ConvBlockSN(bn=False) (reflect padding) is never reached on the reference path")
+        if act not in ('lrelu', None):
+            raise NotImplementedError("only LeakyReLU(0.2) ('lrelu') is implemented on the MI355X path")
+        self.conv = SNConv(dims, in_channel, out_channel, ker_size, padding, stride)
+        self.act = act
+
+    def forward(self, x):
+        return self.conv(x, act=self.act is not None)
+
+
+class FeatureExtractor(nn.Sequential):
+    """num_blocks+1 spectral-norm blocks (reference: networks_3d.py:73-85)."""
+
+    def __init__(self, dims, in_channel, out_channel, ker_size, padding, stride, num_blocks=2, return_linear=False):
+        super().__init__()
+        if return_linear:
+            raise NotImplementedError("return_linear=True is never used on the reference path")
+        self.add_module('conv_block_0', ConvBlockSN(dims, in_channel, out_channel, ker_size, padding, stride))
+        for i in range(num_blocks - 1):
+            self.add_module('conv_block_{}'.format(i + 1), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
+        self.add_module('conv_block_{}'.format(num_blocks), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
+
+
+class EncodeVAE(nn.Module):
+    """features -> (mu, logvar) (reference Encode3DVAE/2DVAE: networks_3d.py:88-107)."""
+
+    def __init__(self, dims, opt, out_dim=None, num_blocks=2):
+        super().__init__()
+        if out_dim is None:
+            output_dim = opt.nfc
+        else:
+            assert type(out_dim) is int
+            output_dim = out_dim
+        self.features = FeatureExtractor(dims, opt.nc_im, opt.nfc, opt.ker_size, opt.ker_size // 2, 1, num_blocks=num_blocks)
+        self.mu = ConvBlock(dims, opt.nfc, output_dim, opt.ker_size, opt.ker_size // 2, 1, bn=False, act=None)
+        self.logvar = ConvBlock(dims, opt.nfc, output_dim, opt.ker_size, opt.ker_size // 2, 1, bn=False, act=None)
+
+    def forward(self, x):
+        features = self.features(x)
+        return self.mu(features), self.logvar(features)
+
+
+def _seven_conv_stack(dims, in_channel, N, opt, padding):
+    """head ConvBlock(in->N) + num_layer ConvBlock(N->N) + tail conv(N->nc_im) (decoder and per-level body blocks)."""
+    seq = nn.Sequential()
+    seq.add_module('head', ConvBlock(dims, in_channel, N, opt.ker_size, padding, stride=1))
+    for i in range(opt.num_layer):
+        seq.add_module('block%d' % i, ConvBlock(dims, N, N, opt.ker_size, padding, stride=1))
+    seq.add_module('tail', Conv(dims, N, opt.nc_im, opt.ker_size, opt.ker_size // 2, 1))
+    return seq
+
+
+class WDiscriminator(nn.Module):
+    """Patch critic: SN(3->N)+LReLU, num_layer x SN(N->N)+LReLU, conv(N->1) (reference: networks_3d.py:163-181)."""
+
+    def __init__(self, dims, opt):
+        super().__init__()
+        self.opt = opt
+        N = int(opt.nfc)
+        self.head = ConvBlockSN(dims, opt.nc_im, N, opt.ker_size, opt.ker_size // 2, stride=1, bn=True, act='lrelu')
+        self.body = nn.Sequential()
+        for i in range(opt.num_layer):
+            self.body.add_module('block%d' % i, ConvBlockSN(dims, N, N, opt.ker_size, opt.ker_size // 2, stride=1, bn=True,
+                                                            act='lrelu'))
+        self.tail = Conv(dims, N, 1, opt.ker_size, 1, 1)
+
+    def forward(self, x):
+        return self.tail(self.body(self.head(x)))
+
+
+class GeneratorHPVAEGAN(nn.Module):
+    """Encoder + VAE decoder + growing list of per-level refinement blocks (reference: networks_3d.py:325-406,
+    networks_2d.py:188-269).  Differences 3-D vs 2-D kept exactly: the 3-D path injects level noise only for levels
+    idx+1 >= vae_levels (networks_3d.py:398), the 2-D path at every level in 'rand' mode (networks_2d.py:261).
+
+    `noise_source`: optional callable(ref_tensor) -> N(0,1) tensor of ref's shape, used for the reparameterisation
+    eps and the per-level noise (tests inject recorded noise; default = utils.generate_noise on the device)."""
+
+    def __init__(self, dims, opt):
+        super().__init__()
+        self.dims = dims
+        self.opt = opt
+        N = int(opt.nfc)
+        self.N = N
+        self.encode = EncodeVAE(dims, opt, out_dim=opt.latent_dim, num_blocks=opt.enc_blocks)
+        self.decoder = _seven_conv_stack(dims, opt.latent_dim, N, opt, opt.padd_size)
+        self.body = nn.ModuleList([])
+        self.noise_source = None
+
+    def init_next_stage(self):
+        if len(self.body) == 0:
+            self.body.append(_seven_conv_stack(self.dims, self.opt.nc_im, self.N, self.opt, self.opt.padd_size))
+        else:
+            self.body.append(copy.deepcopy(self.body[-1]))
+
+    def _noise_like(self, ref):
+        if self.noise_source is not None:
+            return self.noise_source(ref)
+        return hp_utils.generate_noise(ref=ref)
+
+    def _reparameterize(self, mu, logvar):
+        if self.training:
+            return ops.Reparam.apply(mu, logvar, self._noise_like(mu))
+        return self._noise_like(mu)
+
+    def forward(self, video, noise_amp, noise_init=None, sample_init=None, mode='rand'):
+        if sample_init is not None:
+            assert len(self.body) > sample_init[0], "Strating index must be lower than # of body blocks"
+
+        if noise_init is None:
+            mu, logvar = self.encode(video)
+            z_vae = self._reparameterize(mu, logvar)
+        else:
+            z_vae = noise_init
+
+        vae_out = ops.TanhRes.apply(self.decoder(z_vae), None)
+
+        if sample_init is not None:
+            x_prev_out = self.refinement_layers(sample_init[0], sample_init[1], noise_amp, mode)
+        else:
+            x_prev_out = self.refinement_layers(0, vae_out, noise_amp, mode)
+
+        if noise_init is None:
+            return x_prev_out, vae_out, (mu, logvar)
+        return x_prev_out, vae_out
+
+    def _level_size(self, index):
+        if self.dims == 3:
+            return hp_utils.images.level_shape_3d(index, self.opt)
+        return hp_utils.images.level_shape_2d(index, self.opt)
+
+    def refinement_layers(self, start_idx, x_prev_out, noise_amp, mode):
+        for idx, block in enumerate(self.body[start_idx:], start_idx):
+            if self.opt.vae_levels == idx + 1 and not self.opt.train_all:
+                x_prev_out.detach_()
+            size = self._level_size(idx + 1)
+            inject = mode == 'rand' and (self.dims == 2 or self.opt.vae_levels <= idx + 1)
+            if inject:
+                ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *size))
+                noise = self._noise_like(ref)
+                up, up_noisy = ops.UpsampleAC.apply(x_prev_out, tuple(size), noise, float(noise_amp[idx + 1]))
+                x_prev = block(up_noisy)
+            else:
+                up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
+                x_prev = block(up)
+            x_prev_out = ops.TanhRes.apply(x_prev, up)
+        return x_prev_out

@@ -1,0 +1,515 @@
+"""torch.autograd.Function wrappers over the C ABI (include/hpvg.h).
+
+torch is used for device memory, streams and graph bookkeeping only; every arithmetic kernel below is a
+hand-written gfx950 kernel in libhpvg.so.  The convolution family {Conv, ConvBwdData, ConvBwdWeight,
+LReLUMaskMul} is closed under differentiation (each backward is expressed with the other Functions), which is
+what the WGAN-GP double backward through the discriminator needs (reference: modules/utils.py:14-18)."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib
+from .lib import call, ptr, stream
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch buffer shared by all ops on `device` (grown on demand)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def geom(x, w_shape=None):
+    """(B, C, T, H, W) of an NCDHW / NCHW activation."""
+    if x.dim() == 5:
+        B, C, T, H, W = x.shape
+    elif x.dim() == 4:
+        B, C, H, W = x.shape
+        T = 1
+    else:
+        raise RuntimeError("expected a 4-D or 5-D activation, got %s" % (tuple(x.shape),))
+    return B, C, T, H, W
+
+
+def _kt(w_shape):
+    if len(w_shape) == 5:
+        if tuple(w_shape[2:]) != (3, 3, 3):
+            raise RuntimeError("only 3x3x3 kernels are supported on the MI355X path, got %s" % (tuple(w_shape),))
+        return 3
+    if len(w_shape) == 4:
+        if tuple(w_shape[2:]) != (3, 3):
+            raise RuntimeError("only 3x3 kernels are supported on the MI355X path, got %s" % (tuple(w_shape),))
+        return 1
+    raise RuntimeError("bad weight shape %s" % (tuple(w_shape),))
+
+
+# ------------------------------------------------------------------------------------------ raw launches
+def pack_weight(w, flip):
+    """Natural [Co][Ci][taps] weight -> MFMA fragment order (forward, or backward-data when flip)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    KT = _kt(w.shape)
+    cin_k, cout_k = (Co, Ci) if flip else (Ci, Co)
+    n = call("hpvg_conv_wpack_floats", cin_k, cout_k, KT)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    call("hpvg_conv_pack_weight_f32", ptr(_c(w)), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, stream())
+    return wp
+
+
+def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False):
+    """y = conv(f(x), w) (+bias); flip=True runs the backward-data conv of the layer weight w."""
+    x = _c(x)
+    B, C, T, H, W = geom(x)
+    KT = _kt(w.shape)
+    Co_l, Ci_l = w.shape[0], w.shape[1]
+    cin_k, cout_k = (Co_l, Ci_l) if flip else (Ci_l, Co_l)
+    if C != cin_k:
+        raise RuntimeError("conv: input has %d channels, weight expects %d" % (C, cin_k))
+    wp = pack_weight(w, flip)
+    shape = (B, cout_k, T, H, W) if x.dim() == 5 else (B, cout_k, H, W)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    sc = sh = None
+    if in_affine is not None:
+        sc, sh = in_affine
+    call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
+         1 if out_lrelu else 0, B, cin_k, cout_k, T, H, W, KT, stream())
+    return y
+
+
+def conv_bwd_weight_raw(dy, x, w_shape):
+    dy = _c(dy)
+    x = _c(x)
+    B, Co, T, H, W = geom(dy)
+    Ci = x.shape[1]
+    KT = _kt(w_shape)
+    if (Co, Ci) != (w_shape[0], w_shape[1]):
+        raise RuntimeError("conv_bwd_weight: channel mismatch")
+    nbytes = call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT)
+    ws = workspace(nbytes, dy.device)
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    call("hpvg_conv_bwd_weight_f32", ptr(dy), ptr(x), None, None, 0, ptr(dw), 0, ptr(ws), ctypes.c_size_t(ws.numel()),
+         B, Ci, Co, T, H, W, KT, stream())
+    return dw
+
+
+def channel_sum_raw(dy):
+    dy = _c(dy)
+    B, C, T, H, W = geom(dy)
+    out = torch.empty(C, dtype=torch.float32, device=dy.device)
+    call("hpvg_channel_sum_f32", ptr(dy), ptr(out), B, C, ctypes.c_long(T * H * W), stream())
+    return out
+
+
+def _scalar_out(device):
+    return torch.empty(1, dtype=torch.float32, device=device)
+
+
+def _reduce_ws(device):
+    n = call("hpvg_reduce_ws_bytes")
+    return workspace(n, device), n
+
+
+# ------------------------------------------------------------------------------------------ conv family
+class LReLUMaskMul(Function):
+    """dy * (h > 0 ? 1 : 0.2) - leaky_relu_backward on the activated tensor (reference: networks_3d.py:21)."""
+
+    @staticmethod
+    def forward(ctx, dy, h):
+        dy = _c(dy)
+        out = torch.empty_like(dy)
+        call("hpvg_lrelu_mask_mul_f32", ptr(dy), ptr(h), ptr(out), ctypes.c_long(dy.numel()), stream())
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        return LReLUMaskMul.apply(g, h), None
+
+
+class ChannelSum(Function):
+    @staticmethod
+    def forward(ctx, dy):
+        ctx.shape = dy.shape
+        return channel_sum_raw(dy)
+
+    @staticmethod
+    def backward(ctx, g):
+        view = [1, -1] + [1] * (len(ctx.shape) - 2)
+        return g.view(*view).expand(ctx.shape).contiguous()
+
+
+class Conv(Function):
+    """y = conv3x3(x, w) + b, optionally followed by LeakyReLU(0.2) (ConvBlock3DSN / plain tails)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y = conv_fwd_raw(x, w, b, out_lrelu=act)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        if ctx.act:
+            dy = LReLUMaskMul.apply(dy, y)
+        dx = ConvBwdData.apply(dy, w) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeight.apply(dy, x, w.shape) if ctx.needs_input_grad[1] else None
+        db = ChannelSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+class ConvBwdData(Function):
+    """dx = conv(dy, flip/transpose(w)): backward-data of a stride-1 'same' conv."""
+
+    @staticmethod
+    def forward(ctx, dy, w):
+        ctx.save_for_backward(dy, w)
+        return conv_fwd_raw(dy, w, None, flip=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        g = _c(g)
+        ddy = Conv.apply(g, w, None, False) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeight.apply(dy, g, w.shape) if ctx.needs_input_grad[1] else None
+        return ddy, dw
+
+
+class ConvBwdWeight(Function):
+    """dw[o][c][tap] = sum dy[o][n] * x[c][n + off(tap)]."""
+
+    @staticmethod
+    def forward(ctx, dy, x, w_shape):
+        ctx.save_for_backward(dy, x)
+        return conv_bwd_weight_raw(dy, x, w_shape)
+
+    @staticmethod
+    def backward(ctx, gw):
+        dy, x = ctx.saved_tensors
+        gw = _c(gw)
+        ddy = Conv.apply(x, gw, None, False) if ctx.needs_input_grad[0] else None
+        dx = ConvBwdData.apply(dy, gw) if ctx.needs_input_grad[1] else None
+        return ddy, dx, None
+
+
+# ------------------------------------------------------------------------------------------ BatchNorm + LeakyReLU
+class BNAct(Function):
+    """h = LeakyReLU_opt(BatchNorm_train(r)) with running-stat update (ConvBlock3D: networks_3d.py:54-56)."""
+
+    @staticmethod
+    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu):
+        r = _c(r)
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        nws = call("hpvg_bn_ws_bytes", C)
+        ws = workspace(nws, dev)
+        call("hpvg_bn_train_stats_f32", ptr(r), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws),
+             ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
+        h = torch.empty_like(r)
+        call("hpvg_affine_act_f32", ptr(r), ptr(stats[2]), ptr(stats[3]), ptr(h), 1 if lrelu else 0, B, C,
+             ctypes.c_long(S), stream())
+        ctx.save_for_backward(r, stats)
+        ctx.lrelu = lrelu
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        r, stats = ctx.saved_tensors
+        dh = _c(dh)
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        dr = torch.empty_like(r)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        nws = call("hpvg_bn_ws_bytes", C)
+        ws = workspace(nws, dev)
+        call("hpvg_bn_act_bwd_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             1 if ctx.lrelu else 0, ptr(dr), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), ctypes.c_size_t(ws.numel()), B, C,
+             ctypes.c_long(S), stream())
+        return dr, dgb[0], dgb[1], None, None, None, None, None
+
+
+class AffineAct(Function):
+    """y = LeakyReLU_opt(scale[c]*x + shift[c]) - eval-mode BatchNorm apply (running statistics)."""
+
+    @staticmethod
+    def forward(ctx, r, scale, shift, lrelu):
+        r = _c(r)
+        B, C, T, H, W = geom(r)
+        h = torch.empty_like(r)
+        call("hpvg_affine_act_f32", ptr(r), ptr(_c(scale)), ptr(_c(shift)), ptr(h), 1 if lrelu else 0, B, C,
+             ctypes.c_long(T * H * W), stream())
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        raise NotImplementedError("eval-mode BatchNorm backward is not on the reference's train path")
+
+
+# ------------------------------------------------------------------------------------------ spectral norm
+class SpectralNormWeight(Function):
+    """W = W_orig / sigma(W_orig), sigma = u^T W_mat v after one power iteration (u, v updated in place when
+    training).  torch hook semantics: nn.utils.spectral_norm, n_power_iterations=1, eps=1e-12 (networks_3d.py:63)."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, do_iter, eps):
+        w_orig = _c(w_orig)
+        Co = w_orig.shape[0]
+        K = w_orig.numel() // Co
+        dev = w_orig.device
+        sig = torch.empty(2, dtype=torch.float32, device=dev)  # sigma, 1/sigma
+        ws = workspace(Co * 4, dev)
+        call("hpvg_sn_power_iter_f32", ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(sig[1:2]), Co, K,
+             1 if do_iter else 0, float(eps), ptr(ws), ctypes.c_size_t(ws.numel()), stream())
+        w = torch.empty_like(w_orig)
+        call("hpvg_div_scalar_f32", ptr(w_orig), ptr(sig[0:1]), ptr(w), ctypes.c_long(w.numel()), stream())
+        # later forwards overwrite the u/v buffers before this call's backward runs: keep copies (as torch does)
+        ctx.save_for_backward(w_orig, u.clone(), v.clone(), sig)
+        return w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dw):
+        w_orig, u, v, sig = ctx.saved_tensors
+        dw = _c(dw)
+        Co = w_orig.shape[0]
+        K = w_orig.numel() // Co
+        out = torch.empty_like(w_orig)
+        call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(out), Co, K, stream())
+        return out, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ generator glue
+class TanhRes(Function):
+    """y = tanh(x + res)  (res optional): networks_3d.py:377 (vae_out) and :404 (residual refinement)."""
+
+    @staticmethod
+    def forward(ctx, x, res):
+        x = _c(x)
+        if res is not None:
+            res = _c(res)
+        y = torch.empty_like(x)
+        call("hpvg_tanh_fwd_f32", ptr(x), ptr(res), ptr(y), ctypes.c_long(x.numel()), stream())
+        ctx.save_for_backward(y)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(y)
+        call("hpvg_tanh_bwd_f32", ptr(dy), ptr(y), ptr(dx), ctypes.c_long(y.numel()), stream())
+        return dx, (dx if ctx.has_res else None)
+
+
+class UpsampleAC(Function):
+    """Tri/bi-linear resize with align_corners=True to `size`; with `noise`, also returns up + amp*noise
+    (utils/images.py:83-105 + networks_3d.py:395-400)."""
+
+    @staticmethod
+    def forward(ctx, x, size, noise, amp):
+        x = _c(x)
+        B, C, Ti, Hi, Wi = geom(x)
+        if x.dim() == 5:
+            To, Ho, Wo = size
+            oshape = (B, C, To, Ho, Wo)
+        else:
+            Ho, Wo = size
+            To = 1
+            oshape = (B, C, Ho, Wo)
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        yn = None
+        if noise is not None:
+            noise = _c(noise)
+            if tuple(noise.shape) != tuple(oshape):
+                raise RuntimeError("noise shape %s != upsampled shape %s" % (tuple(noise.shape), oshape))
+            yn = torch.empty_like(y)
+        call("hpvg_upsample_linear_ac_f32", ptr(x), ptr(y), ptr(noise), float(amp), ptr(yn), ctypes.c_long(B * C), Ti, Hi,
+             Wi, To, Ho, Wo, stream())
+        ctx.in_shape = x.shape
+        ctx.dims = (B * C, Ti, Hi, Wi, To, Ho, Wo)
+        if yn is None:
+            return y
+        return y, yn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, dyn=None):
+        if dyn is not None and dy is not None:
+            g = dy + dyn
+        else:
+            g = dy if dy is not None else dyn
+        g = _c(g)
+        BC, Ti, Hi, Wi, To, Ho, Wo = ctx.dims
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=g.device)
+        call("hpvg_upsample_linear_ac_bwd_f32", ptr(g), ptr(dx), ctypes.c_long(BC), Ti, Hi, Wi, To, Ho, Wo, stream())
+        return dx, None, None, None
+
+
+class Reparam(Function):
+    """z = eps * exp(0.5*logvar) + mu (networks_3d.py:29-33, training branch)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _c(mu), _c(logvar), _c(eps)
+        z = torch.empty_like(mu)
+        call("hpvg_reparam_fwd_f32", ptr(mu), ptr(logvar), ptr(eps), ptr(z), ctypes.c_long(mu.numel()), stream())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = _c(dz)
+        dlv = torch.empty_like(dz)
+        call("hpvg_reparam_bwd_f32", ptr(dz), ptr(logvar), ptr(eps), ptr(dlv), ctypes.c_long(dz.numel()), stream())
+        return dz, dlv, None
+
+
+# ------------------------------------------------------------------------------------------ losses
+class KL(Function):
+    """mean(-0.5*(1 + logvar - mu^2 - exp(logvar)))  (modules/losses.py:7-9)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _c(mu), _c(logvar)
+        out = _scalar_out(mu.device)
+        ws, n = _reduce_ws(mu.device)
+        call("hpvg_kl_fwd_f32", ptr(mu), ptr(logvar), ptr(out), ptr(ws), ctypes.c_size_t(n), ctypes.c_long(mu.numel()), stream())
+        ctx.save_for_backward(mu, logvar)
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = _c(g).view(1)
+        dmu = torch.empty_like(mu)
+        dlv = torch.empty_like(mu)
+        call("hpvg_kl_bwd_f32", ptr(g), ptr(mu), ptr(logvar), ptr(dmu), ptr(dlv), ctypes.c_long(mu.numel()), stream())
+        return dmu, dlv
+
+
+class MSE(Function):
+    """mean((a-b)^2)  (nn.MSELoss: train_video.py:355)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise RuntimeError("mse: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        out = _scalar_out(a.device)
+        ws, n = _reduce_ws(a.device)
+        call("hpvg_mse_fwd_f32", ptr(a), ptr(b), ptr(out), ptr(ws), ctypes.c_size_t(n), ctypes.c_long(a.numel()), stream())
+        ctx.save_for_backward(a, b)
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g).view(1)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            call("hpvg_mse_bwd_f32", ptr(g), ptr(a), ptr(b), ptr(da), ctypes.c_long(a.numel()), stream())
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(a)
+            call("hpvg_mse_bwd_f32", ptr(g), ptr(b), ptr(a), ptr(db), ctypes.c_long(a.numel()), stream())
+        return da, db
+
+
+class MeanScaled(Function):
+    """sign * mean(x): the WGAN critic terms (train_video.py:170,178,194)."""
+
+    @staticmethod
+    def forward(ctx, x, sign):
+        x = _c(x)
+        out = _scalar_out(x.device)
+        ws, n = _reduce_ws(x.device)
+        call("hpvg_sum_scaled_f32", ptr(x), ptr(out), ctypes.c_double(sign / x.numel()), ptr(ws), ctypes.c_size_t(n),
+             ctypes.c_long(x.numel()), stream())
+        ctx.shape = x.shape
+        ctx.coef = sign / x.numel()
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g).view(1)
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        call("hpvg_fill_scaled_f32", ptr(g), float(ctx.coef), ptr(dx), ctypes.c_long(dx.numel()), stream())
+        return dx, None
+
+
+class GradPenalty(Function):
+    """lambda * mean_{b,voxel} (||g[b,:,voxel]||_2 - 1)^2   (modules/utils.py:18; norm over dim=1)."""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        g = _c(g)
+        B, C, T, H, W = geom(g)
+        out = _scalar_out(g.device)
+        ws, n = _reduce_ws(g.device)
+        call("hpvg_gp_fwd_f32", ptr(g), ptr(out), float(lam), ptr(ws), ctypes.c_size_t(n), B, C, ctypes.c_long(T * H * W),
+             stream())
+        ctx.save_for_backward(g)
+        ctx.lam = lam
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        gout = _c(gout).view(1)
+        B, C, T, H, W = geom(g)
+        dg = torch.empty_like(g)
+        call("hpvg_gp_bwd_f32", ptr(gout), ptr(g), ptr(dg), float(ctx.lam), B, C, ctypes.c_long(T * H * W), stream())
+        return dg, None
+
+
+def lerp(a, b, alpha):
+    """alpha*a + (1-alpha)*b with a device scalar alpha (no autograd: the result becomes a leaf, modules/utils.py:9-10)."""
+    a, b = _c(a.detach()), _c(b.detach())
+    out = torch.empty_like(a)
+    call("hpvg_lerp_f32", ptr(a), ptr(b), ptr(alpha), ptr(out), ctypes.c_long(a.numel()), stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ optimizer primitives
+def sqsum(flat):
+    out = _scalar_out(flat.device)
+    ws, n = _reduce_ws(flat.device)
+    call("hpvg_sqsum_f32", ptr(flat), ptr(out), ptr(ws), ctypes.c_size_t(n), ctypes.c_long(flat.numel()), stream())
+    return out
+
+
+def clip_scale_(flat_grad, sq, max_norm, coef_out=None):
+    call("hpvg_clip_scale_f32", ptr(flat_grad), ctypes.c_long(flat_grad.numel()), ptr(sq), float(max_norm), ptr(coef_out),
+         stream())
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    call("hpvg_adam_step_f32", ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_long(p.numel()), float(lr), float(beta1), float(beta2),
+         float(eps), int(step), stream())

@@ -1,0 +1,113 @@
+/* hpvg.h - C ABI of libhpvg.so, the MI355X (gfx950) kernels behind the HP-VAE-GAN train step.
+ *
+ * Boundary contract: the reference (lior1990/hp-vae-gan, /root/reference) has no
+ * FFI of its own - the hot path sits behind a Python module surface (modules/networks_3d.py,
+ * networks_2d.py, losses.py, utils.py, utils/images.py) whose arithmetic is torch ATen ops.  Each
+ * entry point below replaces one such ATen op (or a fused group) at the call site cited.  The Python
+ * mirror of that module surface (package hp-vae-gan_amd/) binds these with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Rules for every entry point:
+ *   - plain pointers and sizes only; all tensors fp32, contiguous, NCDHW (2-D convs: T = 1, KT = 1);
+ *   - pointers are DEVICE pointers unless stated; the caller owns every buffer, including workspace;
+ *   - never allocates, never synchronises, never throws; work is enqueued on `stream` (a hipStream_t);
+ *   - returns 0 (HPVG_OK) or a negative error code.
+ */
+#ifndef HPVG_H
+#define HPVG_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPVG_OK 0
+#define HPVG_ERR_ARG (-1)
+#define HPVG_ERR_WORKSPACE (-2)
+#define HPVG_ERR_UNSUPPORTED (-3)
+#define HPVG_ERR_LAUNCH (-4)
+
+/* ---- convolution: nn.Conv3d/nn.Conv2d k=3 s=1 p=1 (modules/networks_3d.py:51,63,175,341,362; networks_2d.py:56,68,181,202,223)
+ * KT = 3: 3x3x3 taps, KT = 1: 3x3 taps.  Weights are first packed into MFMA fragment order. */
+size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT);
+/* w: layer weight [Cout_layer][Cin_layer][KT][3][3]; inv_scale: device scalar 1/sigma (spectral norm) or NULL.
+ * transpose_flip=0 -> pack for forward; 1 -> pack for backward-data (a conv with Cin=Cout_layer, Cout=Cin_layer). */
+int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                              int transpose_flip, void* stream);
+/* y = conv(f(x), wp) + bias; f = identity or LeakyReLU_opt(in_scale[c]*x + in_shift[c]) applied before zero padding
+ * (fused BatchNorm-apply of the producing ConvBlock3D, networks_3d.py:54-55); out_lrelu: LeakyReLU(0.2) epilogue
+ * (ConvBlock3DSN, networks_3d.py:59-70). bias may be NULL. */
+int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
+                      int in_lrelu, float* y, int out_lrelu, int B, int Cin, int Cout, int T, int H, int W, int KT,
+                      void* stream);
+int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
+/* dW (natural layout) of the conv above: aten::convolution_backward weight half, reached from
+ * total_loss.backward() / errD_total.backward() (train_video.py:182,200). accumulate!=0: dw += result. */
+size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT);
+int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_scale, const float* in_shift, int in_lrelu,
+                             float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
+                             int W, int KT, void* stream);
+int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
+/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient */
+int hpvg_channel_sum_f32(const float* x, float* out, int B, int C, long S, void* stream);
+
+/* ---- BatchNorm3d/2d, train mode on every forward (networks_3d.py:54), eps 1e-5, momentum 0.1 */
+size_t hpvg_bn_ws_bytes(int C);
+int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* ws,
+                            size_t ws_bytes, int B, int C, long S, void* stream);
+/* y = LeakyReLU_opt(scale[c]*x + shift[c]) (BN apply + nn.LeakyReLU(0.2), networks_3d.py:21,54-56) */
+int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int lrelu, int B, int C, long S,
+                        void* stream);
+/* backward of h = LeakyReLU_opt(BN_train(r)): dr, dgamma, dbeta (native_batch_norm_backward + leaky_relu_backward) */
+int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B,
+                        int C, long S, void* stream);
+/* out = dy * (h > 0 ? 1 : 0.2): leaky_relu_backward on the in-place activated tensor (networks_3d.py:21) */
+int hpvg_lrelu_mask_mul_f32(const float* dy, const float* h, float* out, long n, void* stream);
+
+/* ---- generator glue: tanh / residual (networks_3d.py:377,404), reparameterize (networks_3d.py:29-33) */
+int hpvg_tanh_fwd_f32(const float* x, const float* res /*nullable*/, float* y, long n, void* stream);
+int hpvg_tanh_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream);
+int hpvg_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream);
+int hpvg_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps, float* dlogvar, long n, void* stream);
+
+/* ---- losses: kl_criterion (modules/losses.py:7-9), nn.MSELoss (train_video.py:355), WGAN means (train_video.py:170,178,194) */
+size_t hpvg_reduce_ws_bytes(void);
+int hpvg_kl_fwd_f32(const float* mu, const float* logvar, float* out, void* ws, size_t ws_bytes, long n, void* stream);
+int hpvg_kl_bwd_f32(const float* gout, const float* mu, const float* logvar, float* dmu, float* dlogvar, long n, void* stream);
+int hpvg_mse_fwd_f32(const float* a, const float* b, float* out, void* ws, size_t ws_bytes, long n, void* stream);
+int hpvg_mse_bwd_f32(const float* gout, const float* a, const float* b, float* da, long n, void* stream);
+int hpvg_sum_scaled_f32(const float* x, float* out, double scale, void* ws, size_t ws_bytes, long n, void* stream);
+int hpvg_sqsum_f32(const float* x, float* out, void* ws, size_t ws_bytes, long n, void* stream);
+int hpvg_fill_scaled_f32(const float* gout, float coef, float* out, long n, void* stream);
+
+/* ---- WGAN-GP (modules/utils.py:4-19): interpolate, per-voxel channel norm penalty and its gradient */
+int hpvg_lerp_f32(const float* a, const float* b, const float* alpha, float* out, long n, void* stream);
+int hpvg_gp_fwd_f32(const float* g, float* out, float lambda, void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
+int hpvg_gp_bwd_f32(const float* gout, const float* g, float* dg, float lambda, int B, int C, long S, void* stream);
+
+/* ---- pyramid resize: F.interpolate(mode=tri/bilinear, align_corners=True) (utils/images.py:13,17,24,83-105),
+ * optional fused noise injection yn = y + amp*noise (networks_3d.py:399-400).  BC = batch*channels. */
+int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, float amp, float* yn, long BC, int Ti, int Hi,
+                                int Wi, int To, int Ho, int Wo, void* stream);
+int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
+                                    void* stream);
+
+/* ---- spectral norm (nn.utils.spectral_norm, networks_3d.py:63): one power iteration, sigma, 1/sigma; backward through sigma */
+int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, int Co, int K, int do_iter,
+                           float eps, void* ws, size_t ws_bytes, void* stream);
+/* out = x / s[0]: weight = weight_orig / sigma (torch SpectralNorm.compute_weight) */
+int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream);
+int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
+                    int Co, int K, void* stream);
+
+/* ---- optimizer: clip_grad_norm_ (train_video.py:201) and optim.Adam (train_video.py:55,88) over flat arenas */
+int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, float* coef_out /*nullable, 2 floats*/,
+                        void* stream);
+int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                       int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPVG_H */

@@ -1,0 +1,356 @@
+"""CPU ORACLE for the HP-VAE-GAN train-step hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the product
+package (hp-vae-gan_amd/) never does.  It is a from-scratch functional restatement, on plain torch CPU fp32
+tensors, of the arithmetic the reference (lior1990/hp-vae-gan, /root/reference) performs on this path.  The
+reference's arithmetic lives in a third-party dependency - torch ATen (reference pins pytorch==1.4.0, env.sh:3;
+this image has torch 2.10.0) - so every step below is written out from the published definition of the op and
+cites the reference call site it stands for:
+
+  conv                      nn.Conv3d/2d k3 s1 p1        modules/networks_3d.py:51,63,175,341,362
+  batch_norm_train          nn.BatchNorm3d/2d (train)    modules/networks_3d.py:54
+  leaky_relu                nn.LeakyReLU(0.2)            modules/networks_3d.py:21
+  spectral_norm_weight      nn.utils.spectral_norm       modules/networks_3d.py:63
+  resize_linear_ac          F.interpolate(align_corners) utils/images.py:13,17,24
+  generator_forward         GeneratorHPVAEGAN.forward    modules/networks_3d.py:367-406, networks_2d.py:230-269
+  discriminator_forward     WDiscriminator3D.forward     modules/networks_3d.py:177-181
+  kl_criterion              kl_criterion                 modules/losses.py:7-9
+  gradient_penalty          calc_gradient_penalty        modules/utils.py:4-19
+  train_step                train() loop body            train_video.py:111-202, train_image.py:122-217
+  adam_step / clip_grad     optim.Adam / clip_grad_norm_ train_video.py:55,88,201
+
+Convolution itself is evaluated with torch's CPU conv (the same third-party kernel the reference calls);
+`conv_direct` (pure loops) and oracle/conv_direct.c pin its semantics (cross-correlation, zero padding) on small
+cases.  Derivatives come from torch.autograd over these restated forward formulas.
+
+PARITY PINNING: this oracle is checked in tests/test_oracle_vs_golden.py against golden vectors produced by
+importing the reference's own modules in the build container (tests/golden/make_golden.py, Appendix E of
+SURVEY.md).  The reference ships no tests or fixtures of its own."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.2
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+SN_EPS = 1e-12
+
+
+# ----------------------------------------------------------------------------------------------- geometry
+def adjust_scales2image(size, opt):
+    """utils/images.py:29-36."""
+    opt.num_scales = math.ceil(math.log(math.pow(opt.min_size / size, 1), opt.scale_factor_init)) + 1
+    scale2stop = math.ceil(math.log(min([opt.max_size, size]) / size, opt.scale_factor_init))
+    opt.stop_scale = opt.num_scales - scale2stop
+    opt.scale1 = min(opt.max_size / size, 1)
+    opt.scale_factor = math.pow(opt.min_size / size, 1 / opt.stop_scale)
+
+
+def level_width(index, opt):
+    """utils/images.py:60-64."""
+    return math.ceil(math.pow(opt.scale_factor, opt.stop_scale - index) * opt.img_size)
+
+
+def level_td(index, opt):
+    """utils/images.py:67-80."""
+    fps_index = int((index / opt.stop_scale_time) * (len(opt.sampling_rates) - 1))
+    return opt.fps_lcm // opt.sampling_rates[fps_index] + 1
+
+
+def level_shape(index, opt, dims):
+    w = level_width(index, opt)
+    if dims == 3:
+        return [level_td(index, opt), int(w * opt.ar), w]
+    return [int(w * opt.ar), w]
+
+
+# ----------------------------------------------------------------------------------------------- primitive ops
+def conv(x, w, b=None):
+    """Cross-correlation, stride 1, zero padding 1 on every spatial/temporal side."""
+    if x.dim() == 5:
+        return F.conv3d(x, w, b, stride=1, padding=1)
+    return F.conv2d(x, w, b, stride=1, padding=1)
+
+
+def conv_direct(x, w, b=None):
+    """Pure-loop definition of `conv` (small cases only): y[n,o,p] = b[o] + sum_{c,tap} w[o,c,tap]*x[n,c,p+tap-1]."""
+    x64, w64 = x.double(), w.double()
+    nd = x.dim() - 2
+    pad = [1] * (2 * nd)
+    xp = F.pad(x64, pad)
+    sp = x.shape[2:]
+    y = torch.zeros((x.shape[0], w.shape[0], *sp), dtype=torch.float64)
+    if nd == 3:
+        for dt in range(3):
+            for dh in range(3):
+                for dw in range(3):
+                    patch = xp[:, :, dt:dt + sp[0], dh:dh + sp[1], dw:dw + sp[2]]
+                    y += torch.einsum('ncthw,oc->nothw', patch, w64[:, :, dt, dh, dw])
+    else:
+        for dh in range(3):
+            for dw in range(3):
+                patch = xp[:, :, dh:dh + sp[0], dw:dw + sp[1]]
+                y += torch.einsum('nchw,oc->nohw', patch, w64[:, :, dh, dw])
+    if b is not None:
+        y += b.double().view(1, -1, *([1] * nd))
+    return y.float()
+
+
+def leaky_relu(x):
+    return torch.where(x > 0, x, LRELU_SLOPE * x)
+
+
+def batch_norm_train(x, gamma, beta, running_mean=None, running_var=None):
+    """Per-channel batch statistics over (B, spatial); biased variance for normalisation, unbiased for the
+    running_var update; running <- 0.9*running + 0.1*stat (in place)."""
+    dimsr = [0] + list(range(2, x.dim()))
+    n = x.numel() // x.shape[1]
+    mean = x.mean(dim=dimsr)
+    var = ((x - mean.view(1, -1, *([1] * (x.dim() - 2)))) ** 2).mean(dim=dimsr)
+    shape = (1, -1) + (1,) * (x.dim() - 2)
+    y = (x - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS) * gamma.view(shape) + beta.view(shape)
+    if running_mean is not None:
+        with torch.no_grad():
+            running_mean.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+            running_var.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
+    return y
+
+
+def spectral_norm_weight(w_orig, u, v, training=True):
+    """torch hook semantics (n_power_iterations=1, dim=0): under no-grad v <- normalize(W^T u), u <- normalize(W v)
+    in place on the buffers; then sigma = u^T W v with u, v constants; W = W_orig / sigma."""
+    w_mat = w_orig.reshape(w_orig.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            vn = torch.mv(w_mat.t(), u)
+            vn = vn / max(float(vn.norm()), SN_EPS)
+            un = torch.mv(w_mat, vn)
+            un = un / max(float(un.norm()), SN_EPS)
+            v.copy_(vn)
+            u.copy_(un)
+    uu, vv = u.clone(), v.clone()
+    sigma = torch.dot(uu, torch.mv(w_mat, vv))
+    return w_orig / sigma
+
+
+def resize_linear_ac(x, size):
+    """(Tri/bi)linear resize with align_corners=True: src = dst*(in-1)/(out-1) (fp32), lerp between floor(src) and
+    min(floor(src)+1, in-1), separably over the resized dims (the last len(size) dims)."""
+    nd = len(size)
+    out = x
+    for k in range(nd):
+        dim = x.dim() - nd + k
+        n_in, n_out = out.shape[dim], int(size[k])
+        scale = torch.tensor((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0, dtype=torch.float32)
+        src = scale * torch.arange(n_out, dtype=torch.float32)
+        i0 = src.floor().long().clamp(max=n_in - 1)
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        w1 = (src - i0.float())
+        w0 = 1.0 - w1
+        shape = [1] * out.dim()
+        shape[dim] = n_out
+        out = out.index_select(dim, i0) * w0.view(shape) + out.index_select(dim, i1) * w1.view(shape)
+    return out
+
+
+def kl_criterion(mu, logvar):
+    return (-0.5 * (1 + logvar - mu.pow(2) - logvar.exp())).mean()
+
+
+def mse(a, b):
+    return ((a - b) ** 2).mean()
+
+
+# ----------------------------------------------------------------------------------------------- networks
+# Parameters/buffers are addressed by the reference's state_dict keys.
+def _sn_block(x, P, prefix, training):
+    w = spectral_norm_weight(P[prefix + '.conv.weight_orig'], P[prefix + '.conv.weight_u'], P[prefix + '.conv.weight_v'], training)
+    return leaky_relu(conv(x, w, P[prefix + '.conv.bias']))
+
+
+def _bn_block(x, P, prefix):
+    r = conv(x, P[prefix + '.conv.weight'], P[prefix + '.conv.bias'])
+    if prefix + '.norm.num_batches_tracked' in P:
+        P[prefix + '.norm.num_batches_tracked'] += 1
+    y = batch_norm_train(r, P[prefix + '.norm.weight'], P[prefix + '.norm.bias'], P[prefix + '.norm.running_mean'],
+                         P[prefix + '.norm.running_var'])
+    return leaky_relu(y)
+
+
+def _stack7(x, P, prefix, num_layer):
+    h = _bn_block(x, P, prefix + '.head')
+    for i in range(num_layer):
+        h = _bn_block(h, P, prefix + '.block%d' % i)
+    return conv(h, P[prefix + '.tail.weight'], P[prefix + '.tail.bias'])
+
+
+def encoder_forward(x, P, opt, training=True):
+    h = x
+    for i in range(opt.enc_blocks + 1):
+        h = _sn_block(h, P, 'encode.features.conv_block_%d' % i, training)
+    mu = conv(h, P['encode.mu.conv.weight'], P['encode.mu.conv.bias'])
+    logvar = conv(h, P['encode.logvar.conv.weight'], P['encode.logvar.conv.bias'])
+    return mu, logvar
+
+
+def num_body(P):
+    k = 0
+    while 'body.%d.tail.weight' % k in P:
+        k += 1
+    return k
+
+
+def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True):
+    """GeneratorHPVAEGAN.forward.  `noises` is an iterator yielding the N(0,1) draws in reference order
+    (reparameterisation eps first, then one tensor per noisy level)."""
+    if noise_init is None:
+        mu, logvar = encoder_forward(video, P, opt, training)
+        eps = next(noises)
+        z = eps * torch.exp(0.5 * logvar) + mu if training else eps
+    else:
+        z = noise_init
+    vae_out = torch.tanh(_stack7(z, P, 'decoder', opt.num_layer))
+    x = vae_out
+    for idx in range(num_body(P)):
+        if opt.vae_levels == idx + 1 and not opt.train_all:
+            x = x.detach()
+            if idx == 0:
+                vae_out = x  # reference detaches IN PLACE (networks_3d.py:392): the returned vae_out is cut too
+        up = resize_linear_ac(x, level_shape(idx + 1, opt, dims))
+        inject = mode == 'rand' and (dims == 2 or opt.vae_levels <= idx + 1)
+        inp = up + next(noises) * noise_amp[idx + 1] if inject else up
+        x = torch.tanh(_stack7(inp, P, 'body.%d' % idx, opt.num_layer) + up)
+    if noise_init is None:
+        return x, vae_out, (mu, logvar)
+    return x, vae_out
+
+
+def discriminator_forward(x, P, opt, training=True):
+    h = _sn_block(x, P, 'head', training)
+    for i in range(opt.num_layer):
+        h = _sn_block(h, P, 'body.block%d' % i, training)
+    return conv(h, P['tail.weight'], P['tail.bias'])
+
+
+def gradient_penalty(PD, opt, real, fake, lam, alpha):
+    """modules/utils.py:4-19 with the scalar alpha injected."""
+    xhat = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
+    out = discriminator_forward(xhat, PD, opt)
+    g = torch.autograd.grad(out, xhat, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+    return ((g.norm(2, dim=1) - 1) ** 2).mean() * lam
+
+
+# ----------------------------------------------------------------------------------------------- optimiser
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (L2): coef = min(1, max_norm/(total+1e-6)); returns (total_norm, coef)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total, coef
+
+
+def adam_step(p, g, state, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam (no weight decay, no amsgrad), in place on p."""
+    state['step'] = state.get('step', 0) + 1
+    t = state['step']
+    m = state.setdefault('m', torch.zeros_like(p))
+    v = state.setdefault('v', torch.zeros_like(p))
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** t
+    bc2 = 1 - beta2 ** t
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def g_param_groups(PG, opt, scale_idx):
+    """Adam parameter groups of the generator at stage `scale_idx` (train_video.py:57-86): list of (prefix, lr)."""
+    nb = num_body(PG)
+    groups = []
+    if not opt.train_all:
+        if opt.vae_levels < scale_idx + 1:
+            depth = min(opt.train_depth, nb - opt.vae_levels + 1)
+            blocks = list(range(nb))[-depth:]
+            groups += [('body.%d.' % k, opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, k in enumerate(blocks)]
+        else:
+            groups += [('encode.', opt.lr_g * (opt.lr_scale ** scale_idx)), ('decoder.', opt.lr_g * (opt.lr_scale ** scale_idx))]
+            blocks = list(range(nb))[-opt.train_depth:] if nb else []
+            groups += [('body.%d.' % k, opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, k in enumerate(blocks)]
+    else:
+        if nb < opt.train_depth:
+            groups += [('encode.', opt.lr_g * (opt.lr_scale ** scale_idx)), ('decoder.', opt.lr_g * (opt.lr_scale ** scale_idx))]
+            groups += [('body.%d.' % k, opt.lr_g * (opt.lr_scale ** (nb - 1 - k))) for k in range(nb)]
+        else:
+            blocks = list(range(nb))[-opt.train_depth:]
+            groups += [('body.%d.' % k, opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, k in enumerate(blocks)]
+    return groups
+
+
+def is_param(key):
+    return key.endswith(('.weight', '.bias', '.weight_orig'))
+
+
+# ----------------------------------------------------------------------------------------------- one train iteration
+def train_step(PG, PD, opt, dims, scale_idx, real, real_zero, noise_init, noises, alpha, noise_amps, adam_g, adam_d):
+    """One iteration of train() (train_video.py:111-202) at stage `scale_idx`, with every random draw injected:
+    `noises` = iterator over N(0,1) tensors in reference draw order, `alpha` = the GP scalar.
+    PG / PD: dicts key -> tensor (parameters have requires_grad=True); updated in place.  Returns a dict of losses,
+    gradients (before clipping) and the clip coefficient."""
+    out = {}
+    gparams = {k: v for k, v in PG.items() if is_param(k)}
+    for v in gparams.values():
+        v.grad = None
+    generated, generated_vae, (mu, logvar) = generator_forward(PG, opt, dims, real_zero, noise_amps, mode='rec', noises=noises)
+    if opt.vae_levels >= scale_idx + 1:
+        rec_vae_loss = mse(generated, real) + mse(generated_vae, real_zero)
+        kl_loss = kl_criterion(mu, logvar)
+        total = opt.rec_weight * rec_vae_loss + opt.kl_weight * kl_loss
+        out.update(rec_vae_loss=rec_vae_loss.detach(), kl_loss=kl_loss.detach())
+    else:
+        dparams = {k: v for k, v in PD.items() if is_param(k)}
+        for v in dparams.values():
+            v.grad = None
+        errD_real = -discriminator_forward(real, PD, opt).mean()
+        fake, _ = generator_forward(PG, opt, dims, noise_init, noise_amps, noise_init=noise_init, mode='rand', noises=noises)
+        errD_fake = discriminator_forward(fake.detach(), PD, opt).mean()
+        gp = gradient_penalty(PD, opt, real, fake, opt.lambda_grad, alpha)
+        errD_total = errD_real + errD_fake + gp
+        dgrads = torch.autograd.grad(errD_total, list(dparams.values()), allow_unused=True)
+        out['gradsD'] = {k: (g.clone() if g is not None else None) for k, g in zip(dparams.keys(), dgrads)}
+        for (k, p), g in zip(dparams.items(), dgrads):
+            if g is not None:
+                with torch.no_grad():
+                    adam_step(p, g, adam_d.setdefault(k, {}), opt.lr_d, opt.beta1)
+        rec_loss = mse(generated, real)
+        errG = -discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
+        total = opt.rec_weight * rec_loss + errG
+        out.update(errD_real=errD_real.detach(), errD_fake=errD_fake.detach(), gradient_penalty=gp.detach(),
+                   rec_loss=rec_loss.detach(), errG=errG.detach())
+    keys = list(gparams.keys())
+    grads = torch.autograd.grad(total, [gparams[k] for k in keys], allow_unused=True)
+    out['total_loss'] = total.detach()
+    out['gradsG'] = {k: (g.clone() if g is not None else None) for k, g in zip(keys, grads)}
+    present = [g for g in grads if g is not None]
+    total_norm, coef = clip_grad_norm(present, opt.grad_clip)
+    out['total_norm'], out['clip_coef'] = total_norm, coef
+    gmap = dict(zip(keys, grads))
+    for prefix, lr in g_param_groups(PG, opt, scale_idx):
+        for k in keys:
+            if k.startswith(prefix) and gmap[k] is not None:
+                with torch.no_grad():
+                    adam_step(gparams[k], gmap[k], adam_g.setdefault(k, {}), lr, opt.beta1)
+    return out
+
+
+def noise_amp_for_stage(PG, opt, dims, scale_idx, real, real_zero, noise_amps, noises):
+    """Noise-amplitude calibration at iteration 0 (train_video.py:131-145): appends to noise_amps in place."""
+    if scale_idx == 0:
+        noise_amps.append(1)
+        return
+    noise_amps.append(0)
+    with torch.no_grad():
+        rec, _, _ = generator_forward(PG, opt, dims, real_zero, noise_amps, mode='rec', noises=noises)
+        rmse = torch.sqrt(mse(real, rec))
+    noise_amps[-1] = opt.noise_amp_init * float(rmse) / opt.batch_size

@@ -1,0 +1,327 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (build container only).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; never runs on the GPU box)
+
+The reference's hot-path modules are loaded by file path exactly as SURVEY.md Appendix E describes
+(`utils/images.py`, `modules/networks_3d.py`, `networks_2d.py`, `losses.py`, `utils.py`; a stub `utils` module
+re-exports utils.images.__all__ so that `import utils` inside the networks does not execute utils/__init__.py,
+which needs cv2/torchvision).  The three train_*.py scripts cannot be imported here (cv2, kornia, tensorboard,
+colorama, neptune are absent), so the step sequence of train() (train_video.py:111-202 / train_image.py:122-217)
+is driven by this script around the reference's own classes and functions.  Every random draw made during a step
+(Tensor.normal_, torch.rand) is recorded so that the oracle and the HIP path can be fed the same numbers.
+
+Only DATA is written (inputs + expected outputs, as torch tensors / python scalars); no reference source text."""
+import importlib.util
+import json
+import math
+import os
+import sys
+import types
+
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference():
+    def by_path(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    images = by_path('utils.images', 'utils/images.py')
+    stub = types.ModuleType('utils')
+    for n in images.__all__:
+        setattr(stub, n, getattr(images, n))
+    stub.images = images
+    sys.modules['utils'] = stub
+    n3 = by_path('ref_networks_3d', 'modules/networks_3d.py')
+    n2 = by_path('ref_networks_2d', 'modules/networks_2d.py')
+    losses = by_path('ref_losses', 'modules/losses.py')
+    mutils = by_path('ref_modules_utils', 'modules/utils.py')
+    return images, n3, n2, losses, mutils
+
+
+def make_opt(**kw):
+    o = types.SimpleNamespace(
+        nc_im=3, nfc=8, latent_dim=8, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, stride=1,
+        vae_levels=2, train_all=False, train_depth=1, scale_factor_init=0.75, min_size=16, max_size=40, img_size=40,
+        ar=0.75, sampling_rates=[4, 3, 2, 1], org_fps=24, fps_lcm=12, batch_size=2, lr_g=5e-4, lr_d=5e-4, beta1=0.5,
+        lambda_grad=0.1, rec_weight=10.0, kl_weight=1.0, disc_loss_weight=1.0, lr_scale=0.2, grad_clip=5.0,
+        noise_amp_init=0.1, const_amp=False, device='cpu')
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Recorder:
+    """Record every Tensor.normal_() and torch.rand() result, in call order."""
+
+    def __init__(self):
+        self.normals = []
+        self.rands = []
+
+    def __enter__(self):
+        self._normal = torch.Tensor.normal_
+        self._rand = torch.rand
+        rec = self
+
+        def normal_(t, *a, **k):
+            r = rec._normal(t, *a, **k)
+            rec.normals.append(r.detach().clone())
+            return r
+
+        def rand(*a, **k):
+            r = rec._rand(*a, **k)
+            rec.rands.append(r.detach().clone())
+            return r
+
+        torch.Tensor.normal_ = normal_
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._normal
+        torch.rand = self._rand
+
+
+def perturb(module, gen):
+    """Break the symmetry of fresh / deep-copied blocks: jitter every parameter and BN buffer."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+        for n, b in module.named_buffers():
+            if n.endswith('running_mean'):
+                b.add_(0.1 * torch.randn(b.shape, generator=gen))
+            elif n.endswith('running_var'):
+                b.mul_(1.0 + 0.2 * torch.rand(b.shape, generator=gen))
+
+
+def sd_clone(module):
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def g_param_list(netG, opt, scale_idx):
+    """Parameter groups exactly as train_video.py:57-86 builds them (this driver's own restatement)."""
+    plist = []
+    if not opt.train_all:
+        if opt.vae_levels < scale_idx + 1:
+            train_depth = min(opt.train_depth, len(netG.body) - opt.vae_levels + 1)
+            blocks = netG.body[-train_depth:]
+            plist += [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))} for i, b in enumerate(blocks)]
+        else:
+            plist += [{"params": netG.encode.parameters(), "lr": opt.lr_g * (opt.lr_scale ** scale_idx)},
+                      {"params": netG.decoder.parameters(), "lr": opt.lr_g * (opt.lr_scale ** scale_idx)}]
+            blocks = netG.body[-opt.train_depth:]
+            plist += [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))} for i, b in enumerate(blocks)]
+    else:
+        raise NotImplementedError
+    return plist
+
+
+def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters, seed):
+    """Drive `n_iters` iterations of train() at stage `scale_idx` on the reference modules; record everything."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    images.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(scale_idx):
+        netG.init_next_stage()
+    perturb(netG, gen)
+    gan = opt.vae_levels < scale_idx + 1
+    D = None
+    if gan:
+        D = (nets.WDiscriminator3D if dims == 3 else nets.WDiscriminator2D)(opt)
+        perturb(D, gen)
+        optimizerD = optim.Adam(D.parameters(), lr=opt.lr_d, betas=(opt.beta1, 0.999))
+    optimizerG = optim.Adam(g_param_list(netG, opt, scale_idx), lr=opt.lr_g, betas=(opt.beta1, 0.999))
+
+    def shape(i):
+        w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+        if dims == 3:
+            _, td, _ = images.get_fps_td_by_index(i, opt)
+            return [td, int(w * opt.ar), w]
+        return [int(w * opt.ar), w]
+
+    real = torch.rand(opt.batch_size, 3, *shape(scale_idx), generator=gen) * 2 - 1
+    real_zero = torch.rand(opt.batch_size, 3, *shape(0), generator=gen) * 2 - 1 if scale_idx > 0 else real
+    z_size = [opt.batch_size, opt.latent_dim, *shape(0)]
+    # earlier stages' amplitudes (any plausible values; the last one is calibrated at iteration 0)
+    noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx)]
+    rec_loss_fn = torch.nn.MSELoss()
+
+    fx = {'opt': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, bool, list, str))},
+          'dims': dims, 'scale_idx': scale_idx, 'real': real, 'real_zero': real_zero,
+          'G_init': sd_clone(netG), 'D_init': sd_clone(D) if gan else None,
+          'noise_amps_init': list(noise_amps), 'iters': []}
+
+    for it in range(n_iters):
+        with Recorder() as rec:
+            noise_init = images.generate_noise(size=z_size, device='cpu')
+            if it == 0:
+                with torch.no_grad():
+                    if scale_idx == 0:
+                        noise_amps.append(1)
+                    else:
+                        noise_amps.append(0)
+                        z_rec, _, _ = netG(real_zero, noise_amps, mode="rec")
+                        rmse = torch.sqrt(F.mse_loss(real, z_rec))
+                        noise_amps[-1] = opt.noise_amp_init * rmse.item() / opt.batch_size
+            rec_i = {}
+            generated, generated_vae, (mu, logvar) = netG(real_zero, noise_amps, mode="rec")
+            if not gan:
+                rec_vae_loss = rec_loss_fn(generated, real) + rec_loss_fn(generated_vae, real_zero)
+                kl_loss = losses.kl_criterion(mu, logvar)
+                total_loss = opt.rec_weight * rec_vae_loss + opt.kl_weight * kl_loss
+                rec_i.update(rec_vae_loss=rec_vae_loss.detach().clone(), kl_loss=kl_loss.detach().clone())
+            else:
+                D.zero_grad()
+                errD_real = -D(real).mean()
+                fake, _ = netG(noise_init, noise_amps, noise_init=noise_init, mode="rand")
+                errD_fake = D(fake.detach()).mean()
+                gp = mutils.calc_gradient_penalty(D, real, fake, opt.lambda_grad, 'cpu')
+                errD_total = errD_real + errD_fake + gp
+                errD_total.backward()
+                rec_i['gradsD'] = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in D.named_parameters()}
+                optimizerD.step()
+                rec_loss = rec_loss_fn(generated, real)
+                errG = -D(fake).mean() * opt.disc_loss_weight
+                total_loss = opt.rec_weight * rec_loss + errG
+                rec_i.update(errD_real=errD_real.detach().clone(), errD_fake=errD_fake.detach().clone(),
+                             gradient_penalty=gp.detach().clone(), rec_loss=rec_loss.detach().clone(),
+                             errG=errG.detach().clone(), fake=fake.detach().clone())
+            netG.zero_grad()
+            total_loss.backward()
+            rec_i['gradsG'] = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in netG.named_parameters()}
+            total_norm = torch.nn.utils.clip_grad_norm_(netG.parameters(), opt.grad_clip)
+            optimizerG.step()
+        rec_i.update(total_loss=total_loss.detach().clone(), total_norm=total_norm.detach().clone(),
+                     generated=generated.detach().clone(), generated_vae=generated_vae.detach().clone(),
+                     mu=mu.detach().clone(), logvar=logvar.detach().clone(),
+                     noise_init=rec.normals[0], noises=rec.normals[1:], alpha=(rec.rands[0] if rec.rands else None),
+                     noise_amps=list(noise_amps), G_after=sd_clone(netG), D_after=sd_clone(D) if gan else None)
+        fx['iters'].append(rec_i)
+    return fx
+
+
+def op_fixtures(images, n3, n2, losses, mutils):
+    """Per-op fixtures on odd shapes (halo bugs), produced by the reference's own block classes."""
+    gen = torch.Generator().manual_seed(7)
+    out = {}
+
+    def block_case(name, blk, x):
+        perturb(blk, gen)
+        x = x.clone().requires_grad_(True)
+        sd0 = sd_clone(blk)
+        y = blk(x)
+        gy = torch.randn(y.shape, generator=gen)
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), grad_outputs=gy)
+        out[name] = {'x': x.detach().clone(), 'sd_before': sd0, 'y': y.detach().clone(), 'gy': gy,
+                     'dx': grads[0].clone(), 'dparams': {n: g.clone() for (n, _), g in zip(blk.named_parameters(), grads[1:])},
+                     'sd_after': {k: v for k, v in sd_clone(blk).items() if not torch.equal(v, sd0[k])}}
+
+    torch.manual_seed(11)
+    block_case('convblock3d_3_8', n3.ConvBlock3D(3, 8, 3, 1, 1), torch.randn(2, 3, 5, 7, 9, generator=gen))
+    block_case('convblock3d_64_64', n3.ConvBlock3D(64, 64, 3, 1, 1), torch.randn(2, 64, 3, 5, 6, generator=gen))
+    block_case('convblock3d_128_8', n3.ConvBlock3D(128, 8, 3, 1, 1), torch.randn(1, 128, 2, 4, 5, generator=gen))
+    block_case('convblock3d_8_128_plain', n3.ConvBlock3D(8, 128, 3, 1, 1, bn=False, act=None), torch.randn(1, 8, 2, 5, 4, generator=gen))
+    block_case('convblock3dsn_3_64', n3.ConvBlock3DSN(3, 64, 3, 1, 1), torch.randn(2, 3, 4, 6, 7, generator=gen))
+    block_case('convblock3dsn_16_24', n3.ConvBlock3DSN(16, 24, 3, 1, 1), torch.randn(1, 16, 3, 4, 7, generator=gen))
+    block_case('convblock2d_3_64', n2.ConvBlock2D(3, 64, 3, 1, 1), torch.randn(2, 3, 11, 13, generator=gen))
+    block_case('convblock2d_64_64', n2.ConvBlock2D(64, 64, 3, 1, 1), torch.randn(2, 64, 9, 10, generator=gen))
+    block_case('convblock2dsn_64_64', n2.ConvBlock2DSN(64, 64, 3, 1, 1), torch.randn(2, 64, 7, 12, generator=gen))
+    block_case('tail3d_64_3', torch.nn.Conv3d(64, 3, 3, 1, 1), torch.randn(2, 64, 3, 6, 5, generator=gen))
+    block_case('tail3d_64_1', torch.nn.Conv3d(64, 1, 3, padding=1, stride=1), torch.randn(2, 64, 2, 5, 7, generator=gen))
+
+    # pyramid resize through the reference's upscale / upscale_2d (non-integer ratios)
+    opt = make_opt(img_size=256, min_size=32, max_size=256, ar=0.5625)
+    images.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    for name, idx, shp in (('upscale3d_l1', 1, (2, 3, 4, 18, 33)), ('upscale3d_l6', 6, (1, 1, 5, 57, 102))):
+        x = torch.randn(*shp, generator=gen, requires_grad=True)
+        y = images.upscale(x, idx, opt)
+        gy = torch.randn(y.shape, generator=gen)
+        (dx,) = torch.autograd.grad(y, x, gy)
+        out[name] = {'x': x.detach().clone(), 'index': idx, 'opt': {'img_size': 256, 'min_size': 32, 'max_size': 256, 'ar': 0.5625},
+                     'y': y.detach().clone(), 'gy': gy, 'dx': dx.clone()}
+    opt2 = make_opt(img_size=256, min_size=32, max_size=256, ar=0.75)
+    images.adjust_scales2image(opt2.img_size, opt2)
+    x = torch.randn(2, 3, 24, 33, generator=gen, requires_grad=True)
+    y = images.upscale_2d(x, 1, opt2)
+    gy = torch.randn(y.shape, generator=gen)
+    (dx,) = torch.autograd.grad(y, x, gy)
+    out['upscale2d_l1'] = {'x': x.detach().clone(), 'index': 1, 'opt': {'img_size': 256, 'min_size': 32, 'max_size': 256, 'ar': 0.75},
+                           'y': y.detach().clone(), 'gy': gy, 'dx': dx.clone()}
+
+    # KL + reparameterize
+    mu = torch.randn(2, 8, 2, 3, 4, generator=gen, requires_grad=True)
+    lv = (0.3 * torch.randn(2, 8, 2, 3, 4, generator=gen)).requires_grad_(True)
+    kl = losses.kl_criterion(mu, lv)
+    dmu, dlv = torch.autograd.grad(kl, [mu, lv])
+    out['kl'] = {'mu': mu.detach().clone(), 'logvar': lv.detach().clone(), 'kl': kl.detach().clone(), 'dmu': dmu.clone(), 'dlogvar': dlv.clone()}
+    with Recorder() as rec:
+        z = n3.reparameterize(mu, lv, True)
+    gz = torch.randn(z.shape, generator=gen)
+    dmu, dlv = torch.autograd.grad(z, [mu, lv], gz)
+    out['reparam'] = {'mu': mu.detach().clone(), 'logvar': lv.detach().clone(), 'eps': rec.normals[0], 'z': z.detach().clone(), 'gz': gz,
+                      'dmu': dmu.clone(), 'dlogvar': dlv.clone()}
+
+    # gradient penalty with second-order gradients on every D parameter
+    dopt = make_opt(nfc=8)
+    torch.manual_seed(5)
+    D = n3.WDiscriminator3D(dopt)
+    perturb(D, gen)
+    sd0 = sd_clone(D)
+    real = torch.randn(2, 3, 3, 6, 7, generator=gen)
+    fake = torch.randn(2, 3, 3, 6, 7, generator=gen)
+    with Recorder() as rec:
+        gp = mutils.calc_gradient_penalty(D, real, fake, 0.1, 'cpu')
+    D.zero_grad()
+    gp.backward()
+    out['gp3d'] = {'opt': {'nfc': 8, 'num_layer': 5, 'nc_im': 3, 'ker_size': 3}, 'D_before': sd0, 'real': real, 'fake': fake,
+                   'alpha': rec.rands[0], 'gp': gp.detach().clone(),
+                   'grads': {n: (p.grad.clone() if p.grad is not None else None) for n, p in D.named_parameters()},
+                   'D_after': sd_clone(D)}
+    return out
+
+
+def table_fixtures(images):
+    rows = []
+    for img_size, min_size, max_size, ar in ((256, 32, 256, 0.5625), (256, 32, 256, 0.75), (256, 48, 256, 0.5625), (64, 32, 256, 0.75),
+                                             (40, 16, 40, 0.75), (128, 32, 256, 0.5625)):
+        opt = make_opt(img_size=img_size, min_size=min_size, max_size=max_size, ar=ar)
+        images.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        levels = []
+        for i in range(opt.stop_scale + 1):
+            w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+            fps, td, fi = images.get_fps_td_by_index(i, opt)
+            levels.append({'index': i, 'w': w, 'h': int(w * ar), 'td': td, 'fps': fps, 'fps_index': fi})
+        rows.append({'img_size': img_size, 'min_size': min_size, 'max_size': max_size, 'ar': ar, 'num_scales': opt.num_scales,
+                     'stop_scale': opt.stop_scale, 'scale1': opt.scale1, 'scale_factor': opt.scale_factor, 'levels': levels})
+    return rows
+
+
+def main():
+    images, n3, n2, losses, mutils = load_reference()
+    torch.set_num_threads(1)
+    with open(os.path.join(OUT, 'tables.json'), 'w') as f:
+        json.dump(table_fixtures(images), f, indent=1)
+    torch.save(op_fixtures(images, n3, n2, losses, mutils), os.path.join(OUT, 'ops.pt'))
+    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 1, 1, seed=100), os.path.join(OUT, 'step3d_vae_s1.pt'))
+    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 0, 1, seed=101), os.path.join(OUT, 'step3d_vae_s0.pt'))
+    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 3, 1, seed=102), os.path.join(OUT, 'step3d_gan_s3.pt'))
+    torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=1), 2, 2, 2, seed=103), os.path.join(OUT, 'step2d_gan_s2.pt'))
+    torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=104), os.path.join(OUT, 'step2d_vae_s1.pt'))
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/hpvg_oracle.py) against golden vectors generated from the reference import
+(tests/golden/make_golden.py).  Tolerance: 1e-3 relative as stated in BASELINE.json's north_star; the observed
+agreement is ~1e-6 because both sides run torch CPU fp32 kernels."""
+import json
+import os
+
+import pytest
+import torch
+
+from helpers import GOLDEN, assert_close, load_golden, opt_from, oracle_state
+from oracle import hpvg_oracle as O
+
+TIGHT = 2e-5
+
+
+def test_tables_match_reference():
+    rows = json.load(open(os.path.join(GOLDEN, "tables.json")))
+    for row in rows:
+        opt = opt_from(dict(min_size=row["min_size"], max_size=row["max_size"], img_size=row["img_size"], ar=row["ar"],
+                            scale_factor_init=0.75, sampling_rates=[4, 3, 2, 1], fps_lcm=12, org_fps=24))
+        O.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        assert opt.num_scales == row["num_scales"] and opt.stop_scale == row["stop_scale"]
+        assert opt.scale_factor == row["scale_factor"] and opt.scale1 == row["scale1"]
+        for lv in row["levels"]:
+            assert O.level_width(lv["index"], opt) == lv["w"]
+            assert O.level_shape(lv["index"], opt, 3) == [lv["td"], lv["h"], lv["w"]]
+            assert O.level_shape(lv["index"], opt, 2) == [lv["h"], lv["w"]]
+
+
+def _run_block(name, fx):
+    sd = fx["sd_before"]
+    P = {("blk." + k): v.clone() for k, v in sd.items()}
+    for k in P:
+        if O.is_param(k):
+            P[k].requires_grad_(True)
+    x = fx["x"].clone().requires_grad_(True)
+    if name.startswith("tail"):
+        y = O.conv(x, P["blk.weight"], P["blk.bias"])
+    elif "sn" in name:
+        y = O._sn_block(x, P, "blk", True)
+    elif name.endswith("plain"):
+        y = O.conv(x, P["blk.conv.weight"], P["blk.conv.bias"])
+    else:
+        y = O._bn_block(x, P, "blk")
+    params = [k for k in P if O.is_param(k)]
+    grads = torch.autograd.grad(y, [x] + [P[k] for k in params], grad_outputs=fx["gy"])
+    return y, grads[0], {k[4:]: g for k, g in zip(params, grads[1:])}, {k[4:]: v for k, v in P.items()}
+
+
+@pytest.mark.parametrize("name", ["convblock3d_3_8", "convblock3d_64_64", "convblock3d_128_8", "convblock3d_8_128_plain",
+                                  "convblock3dsn_3_64", "convblock3dsn_16_24", "convblock2d_3_64", "convblock2d_64_64",
+                                  "convblock2dsn_64_64", "tail3d_64_3", "tail3d_64_1"])
+def test_blocks(name):
+    fx = load_golden("ops.pt")[name]
+    y, dx, dparams, P = _run_block(name, fx)
+    assert_close(y, fx["y"], TIGHT, name + ".y")
+    assert_close(dx, fx["dx"], TIGHT, name + ".dx")
+    for k, g in fx["dparams"].items():
+        # the bias of a conv that feeds BatchNorm has an exactly-zero true gradient (BN removes the mean): both sides
+        # hold rounding noise there, so it is compared on the scale of the layer's weight gradient
+        atol = 1e-4 * float(fx["dparams"]["conv.weight"].abs().max()) if (k == "conv.bias" and "norm.weight" in fx["dparams"]) else 1e-6
+        assert_close(dparams[k], g, TIGHT, name + ".d" + k, atol=atol)
+    for k, v in fx["sd_after"].items():  # BN running stats, SN u/v, num_batches_tracked
+        assert_close(P[k].float(), v.float(), TIGHT, name + ".after." + k)
+
+
+def test_conv_direct_definition():
+    torch.manual_seed(0)
+    x3, w3, b3 = torch.randn(2, 3, 3, 4, 5), torch.randn(4, 3, 3, 3, 3), torch.randn(4)
+    assert_close(O.conv(x3, w3, b3), O.conv_direct(x3, w3, b3), 1e-5, "conv3d")
+    x2, w2 = torch.randn(2, 5, 6, 7), torch.randn(3, 5, 3, 3)
+    assert_close(O.conv(x2, w2), O.conv_direct(x2, w2), 1e-5, "conv2d")
+
+
+@pytest.mark.parametrize("name,dims", [("upscale3d_l1", 3), ("upscale3d_l6", 3), ("upscale2d_l1", 2)])
+def test_resize(name, dims):
+    fx = load_golden("ops.pt")[name]
+    o = fx["opt"]
+    opt = opt_from(dict(min_size=o["min_size"], max_size=o["max_size"], img_size=o["img_size"], ar=o["ar"], scale_factor_init=0.75,
+                        sampling_rates=[4, 3, 2, 1], fps_lcm=12, org_fps=24))
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    x = fx["x"].clone().requires_grad_(True)
+    y = O.resize_linear_ac(x, O.level_shape(fx["index"], opt, dims))
+    assert_close(y, fx["y"], TIGHT, name + ".y")
+    (dx,) = torch.autograd.grad(y, x, fx["gy"])
+    assert_close(dx, fx["dx"], TIGHT, name + ".dx")
+
+
+def test_kl_and_reparam():
+    ops = load_golden("ops.pt")
+    fx = ops["kl"]
+    mu, lv = fx["mu"].clone().requires_grad_(True), fx["logvar"].clone().requires_grad_(True)
+    kl = O.kl_criterion(mu, lv)
+    assert_close(kl, fx["kl"], TIGHT, "kl")
+    dmu, dlv = torch.autograd.grad(kl, [mu, lv])
+    assert_close(dmu, fx["dmu"], TIGHT, "kl.dmu")
+    assert_close(dlv, fx["dlogvar"], TIGHT, "kl.dlogvar")
+    fx = ops["reparam"]
+    z = fx["eps"] * torch.exp(0.5 * fx["logvar"]) + fx["mu"]
+    assert_close(z, fx["z"], TIGHT, "reparam.z")
+
+
+def test_gradient_penalty_second_order():
+    fx = load_golden("ops.pt")["gp3d"]
+    opt = opt_from(dict(fx["opt"]))
+    PD = oracle_state(fx["D_before"])
+    gp = O.gradient_penalty(PD, opt, fx["real"], fx["fake"], 0.1, fx["alpha"].reshape(()))
+    assert_close(gp, fx["gp"], TIGHT, "gp")
+    keys = [k for k in PD if O.is_param(k)]
+    grads = torch.autograd.grad(gp, [PD[k] for k in keys], allow_unused=True)
+    for k, g in zip(keys, grads):
+        ref = fx["grads"][k]
+        if ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+        elif float(ref.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) <= 1e-9, k
+        else:
+            assert_close(g, ref, 1e-4, "gp.grad." + k, atol=1e-9)
+    for k, v in fx["D_after"].items():
+        if k.endswith(("weight_u", "weight_v")):
+            assert_close(PD[k], v, TIGHT, "gp.after." + k)
+
+
+def bn_bias_atol(k, grads):
+    """Absolute slack for conv biases that feed a BatchNorm (true gradient exactly 0, see test_blocks)."""
+    if k.endswith(".conv.bias") and (k[:-len("conv.bias")] + "norm.weight") in grads:
+        return 1e-4 * float(grads[k[:-len("bias")] + "weight"].abs().max())
+    return 1e-7
+
+
+def _run_stage(fname):
+    fx = load_golden(fname)
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    dims, s = fx["dims"], fx["scale_idx"]
+    PG = oracle_state(fx["G_init"])
+    PD = oracle_state(fx["D_init"]) if fx["D_init"] is not None else None
+    amps = list(fx["noise_amps_init"])
+    adam_g, adam_d = {}, {}
+    for it, rec in enumerate(fx["iters"]):
+        noises = iter(rec["noises"])
+        if it == 0:
+            O.noise_amp_for_stage(PG, opt, dims, s, fx["real"], fx["real_zero"], amps, noises)
+        assert amps == pytest.approx(rec["noise_amps"], rel=1e-5)
+        alpha = rec["alpha"].reshape(()) if rec["alpha"] is not None else None
+        out = O.train_step(PG, PD, opt, dims, s, fx["real"], fx["real_zero"], rec["noise_init"], noises, alpha, amps, adam_g, adam_d)
+        yield fx, rec, out, PG, PD
+
+
+@pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt"])
+def test_train_step(fname):
+    for it, (fx, rec, out, PG, PD) in enumerate(_run_stage(fname)):
+        for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG"):
+            if k in rec:
+                assert_close(out[k], rec[k], 1e-4, fname + "." + k)
+        assert_close(out["total_norm"], rec["total_norm"], 1e-4, fname + ".total_norm")
+        for k, g in rec["gradsG"].items():
+            mine = out["gradsG"][k]
+            if g is None:
+                assert mine is None, k
+            else:
+                assert_close(mine, g, 2e-4, fname + ".gradG." + k, atol=bn_bias_atol(k, rec["gradsG"]))
+        if "gradsD" in rec:
+            for k, g in rec["gradsD"].items():
+                mine = out["gradsD"][k]
+                if g is None:
+                    assert mine is None or float(mine.abs().max()) == 0.0, k
+                else:
+                    assert_close(mine, g, 2e-4, fname + ".gradD." + k, atol=1e-7)
+        # post-step state: Adam moves each weight by ~lr*sign(g); allow a few lr of absolute slack
+        lr = fx["opt"]["lr_g"] * (it + 1)
+        for k, v in rec["G_after"].items():
+            assert_close(PG[k].float(), v.float(), 1e-4, fname + ".G_after." + k, atol=2 * lr)
+        if rec["D_after"] is not None:
+            for k, v in rec["D_after"].items():
+                assert_close(PD[k].float(), v.float(), 1e-4, fname + ".D_after." + k, atol=2 * lr)
