@@ -1,0 +1,279 @@
+"""bench.py - HP-VAE-GAN train-step throughput on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): train_video.py air_balloons 13 frames @
+256x144, --vae-levels 3, defaults (nfc 64, latent 128, batch 2, fp32) => 10 pyramid stages.
+The mp4 is absent from the reference checkout, so inputs are synthetic U(-1,1) tensors of the exact stage shapes and
+weights are random-init (default torch init), as SURVEY.md 8(d) prescribes.
+
+One "step" = one train iteration (train_video.py:111-202) at EVERY pyramid stage 0..9, inputs resident in HBM.
+value = stage-iterations per second over the timed region (10*K / seconds); per-stage it/s are reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def video_opt(device, **kw):
+    o = types.SimpleNamespace(
+        dims=3, nc_im=3, nfc=64, latent_dim=128, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, stride=1,
+        vae_levels=3, train_all=False, train_depth=1, scale_factor_init=0.75, min_size=32, max_size=256, img_size=256,
+        ar=144.0 / 256.0, sampling_rates=[4, 3, 2, 1], org_fps=24, fps_lcm=12, batch_size=2, lr_g=5e-4, lr_d=5e-4, beta1=0.5,
+        lambda_grad=0.1, rec_weight=10.0, kl_weight=1.0, disc_loss_weight=1.0, lr_scale=0.2, grad_clip=5.0,
+        noise_amp_init=0.1, const_amp=False, device=device, generator="GeneratorHPVAEGAN", discriminator="WDiscriminator3D",
+        niter=1)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def stage_shapes(opt, geom):
+    geom.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    return [geom.level_shape(i, opt) for i in range(opt.stop_scale + 1)]
+
+
+class _HipGeom:
+    @staticmethod
+    def adjust_scales2image(size, opt):
+        from hp_vae_gan_amd import utils as hu
+        hu.adjust_scales2image(size, opt)
+
+    @staticmethod
+    def level_shape(i, opt):
+        from hp_vae_gan_amd import utils as hu
+        return hu.images.level_shape_3d(i, opt)
+
+
+def build_gpu_stages(device, stages):
+    """One StageTrainer per pyramid stage with synthetic resident inputs (setup is outside the timed region)."""
+    import copy
+    from hp_vae_gan_amd import train as hp_train
+    from hp_vae_gan_amd.modules import networks_3d
+    torch.manual_seed(0)
+    base = video_opt(device)
+    shapes = stage_shapes(base, _HipGeom)
+    proto = networks_3d.GeneratorHPVAEGAN(base)
+    out = []
+    for s in range(base.stop_scale + 1):
+        if s > 0:
+            proto.init_next_stage()
+        if s not in stages:
+            continue
+        opt = video_opt(device)
+        _HipGeom.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        opt.scale_idx = s
+        opt.Noise_Amps = [1] + [0.05] * max(0, s - 1)
+        netG = copy.deepcopy(proto)
+        netG.opt = opt
+        netG.to(device)
+        g = torch.Generator().manual_seed(100 + s)
+        real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
+        real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
+        trainer = hp_train.StageTrainer(opt, netG)
+        out.append((s, trainer, real, real_zero))
+    return out, shapes
+
+
+def cpu_baseline(stages, threads):
+    """The CPU oracle (port of the reference path, oracle/hpvg_oracle.py) timed on the host: one warm-up and one timed
+    iteration per sampled stage, same shapes / hyper-parameters, torch CPU fp32 with `threads` threads."""
+    from oracle import hpvg_oracle as O
+    from hp_vae_gan_amd.modules import networks_3d
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    base = video_opt("cpu")
+    O.adjust_scales2image(base.img_size, base)
+    base.stop_scale_time = base.stop_scale
+    proto = networks_3d.GeneratorHPVAEGAN(base)  # parameter containers only (state_dict layout); compute is the oracle's
+    per_stage = {}
+    for s in range(max(stages) + 1):
+        if s > 0:
+            proto.init_next_stage()
+        if s not in stages:
+            continue
+        opt = video_opt("cpu")
+        O.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        PG = {k: v.clone() for k, v in proto.state_dict().items()}
+        for k in PG:
+            if O.is_param(k):
+                PG[k].requires_grad_(True)
+        PD = None
+        if opt.vae_levels < s + 1:
+            D = networks_3d.WDiscriminator3D(opt)
+            PD = {k: v.clone() for k, v in D.state_dict().items()}
+            for k in PD:
+                if O.is_param(k):
+                    PD[k].requires_grad_(True)
+        g = torch.Generator().manual_seed(100 + s)
+        shp = O.level_shape(s, opt, 3)
+        real = torch.rand(opt.batch_size, 3, *shp, generator=g) * 2 - 1
+        real_zero = torch.rand(opt.batch_size, 3, *O.level_shape(0, opt, 3), generator=g) * 2 - 1 if s > 0 else real
+        amps = [1] + [0.05] * s
+        zshape = [opt.batch_size, opt.latent_dim, *O.level_shape(0, opt, 3)]
+
+        def noise_stream():
+            while True:
+                yield None
+
+        class Lazy:
+            """N(0,1) draws of whatever shape the oracle asks for next (shape inferred at use)."""
+
+            def __init__(self):
+                self.q = []
+
+        adam_g, adam_d = {}, {}
+
+        def one_iter():
+            ni = torch.randn(zshape)
+            shapes_needed = [zshape] + [[opt.batch_size, 3, *O.level_shape(i, opt, 3)] for i in range(1, s + 1) if opt.vae_levels <= i]
+            noises = iter([torch.randn(x) for x in shapes_needed])
+            return O.train_step(PG, PD, opt, 3, s, real, real_zero, ni, noises, torch.rand(()), amps, adam_g, adam_d)
+
+        one_iter()  # warm-up
+        t0 = time.perf_counter()
+        one_iter()
+        per_stage[s] = time.perf_counter() - t0
+    return per_stage
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--stages", type=str, default="0-9", help="pyramid stages in a step, e.g. 0-9 or 9")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stages", type=str, default="0-5")
+    args = ap.parse_args()
+
+    def parse(r):
+        a, _, b = r.partition("-")
+        return list(range(int(a), int(b or a) + 1))
+
+    stages = parse(args.stages)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import hp_vae_gan_amd  # noqa: F401  (fails loudly if libhpvg.so is missing)
+    from hp_vae_gan_amd import ops
+
+    if world > 1:
+        from hp_vae_gan_amd import pipeline
+        runner = pipeline.build_bench_runner(video_opt, stages, device, rank, world)
+    else:
+        built, shapes = build_gpu_stages(device, stages)
+
+        class Runner:
+            def step(self):
+                for s, trainer, real, real_zero in built:
+                    trainer.step(real, real_zero)
+
+            def timed_stage(self, idx):
+                s, trainer, real, real_zero = built[idx]
+                trainer.step(real, real_zero)
+                return s
+
+            n = len(built)
+        runner = Runner()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    # ---- timed region: exactly K steps; the dominant kernel's launches are bracketed by HIP events on the launch stream
+    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == 3 and not g["flip"])
+    ops.set_kernel_timer(timer)
+    stage_ev = {}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        for i in range(runner.n):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            s = runner.timed_stage(i)
+            e1.record()
+            stage_ev.setdefault(s, []).append((e0, e1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        nstage = len(stages)
+        per_stage = {str(s): (1000.0 / (sum(a.elapsed_time(b) for a, b in ev) / len(ev))) for s, ev in stage_ev.items()}
+        # dominant kernel: the 64->64 3x3x3 implicit-GEMM conv at the finest resident stage
+        roof = None
+        by_shape = timer.summary()
+        if by_shape:
+            key = max(by_shape, key=lambda k: k[2] * k[3] * k[4])
+            ms, n = by_shape[key]
+            B, C, T, H, W = key
+            flops = 2.0 * B * 64 * 64 * 27 * T * H * W
+            achieved = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<8,3,2,4> (64->64 3x3x3 fwd, fp32 v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "shape": list(key),
+                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cs = [s for s in parse(args.cpu_stages) if s in stages]
+            if cs:
+                threads = min(os.cpu_count() or 1, 16)
+                per = cpu_baseline(cs, threads)
+                tot = sum(per.values())
+                gpu_same = sum(1.0 / per_stage[str(s)] for s in cs)
+                cpu = {"value": round(len(cs) / tot, 4), "unit": "stage-iterations/s", "cores": threads, "kind": "port",
+                       "sample": "1 warm-up + 1 timed iteration of the oracle train step at stages %s (same shapes, B=2, fp32)" % cs,
+                       "per_stage_it_s": {str(s): round(1.0 / t, 4) for s, t in per.items()},
+                       "gpu_value_same_sample": round(len(cs) / gpu_same, 3)}
+        line = {
+            "metric": "train iters/sec per pyramid scale, air_balloons 13f@144p",
+            "value": round(nstage * args.steps / elapsed, 4), "unit": "stage-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2]); "
+                                   "step = 1 train iteration at each pyramid stage %s" % args.stages,
+                       "stages": stages, "parallelism": "single GPU" if world == 1 else "level pipeline x%d" % world},
+            "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

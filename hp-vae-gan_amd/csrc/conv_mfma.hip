@@ -221,7 +221,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   const int tap = r % taps; r /= taps;
   const int ch = (int)r;
   float val = 0.f;
-  if (ch < nchunk) {  // else: tail padding (one extra tap block) stays zero
+  if (ch < nchunk) {  // else: tail padding stays zero
     const int o = mb * 32 + (lane & 31);
     const int c = ch * CC + 2 * cp + (lane >> 5);
     if (o < Cout_k && c < Cin_k) {
@@ -272,7 +272,7 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT) {
         const double waves = nwg <= slots ? 1.0 : (double)nwg / (double)slots;
         // per-WG time ~ MFMA rounds (scaled by m-tiles) + fixed staging/sync overhead
         const double per = (double)NB * MB + 0.6 + 0.002 * (Th + 2) * RS;
-        const double cost = waves * per;
+        const double cost = waves * per + 5e-4 * (double)nwg;  // tie-break: fewer, fuller workgroups
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
           best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds};
@@ -323,7 +323,7 @@ size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) {
   const int nchunk = hpvg_cdiv(Cin, CC);
   const int mbtot = hpvg_cdiv(Cout, 32);
   const size_t per_tap = (size_t)mbtot * 64 * (CC / 2);
-  return ((size_t)nchunk * KT * 9 + 1) * per_tap;  // +1 tap of zero tail padding (prefetch)
+  return ((size_t)nchunk * KT * 9 + 2) * per_tap;  // +2 taps of zero tail padding (A prefetch runs one tap / one m-tile ahead)
 }
 
 // w: natural layout of the LAYER weight [Cout_layer][Cin_layer][KT][3][3].

@@ -466,8 +466,8 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
   }
 }
 
-// dW_orig = (dW_eff - (sum(dW_eff*W_orig)/sigma^2) * sigma * u v^T / sigma ... ) see DESIGN: W_eff = W/sigma
-//   dW_orig[o][k] = (dW_eff[o][k] - (s/sigma) * u[o] v[k]) / sigma,   s = sum dW_eff .* W_orig / sigma
+// backward of W = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
+//   dW_orig[o][k] = dW[o][k]/sigma - (sum(dW .* W_orig)/sigma^2) * u[o] v[k]
 __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ dweff, const float* __restrict__ worig,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        const float* __restrict__ sigma, float* __restrict__ dworig, int Co,
@@ -478,10 +478,10 @@ __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ 
   for (long i = threadIdx.x; i < n; i += 1024) acc += (double)dweff[i] * worig[i];
   const double dot = block1024_sum(acc, sh);
   const float sg = sigma[0];
-  const float coef = (float)(dot / ((double)sg * sg));  // = sum(dW_eff .* W_eff) / sigma
+  const float coef = (float)(dot / ((double)sg * sg));
   for (long i = threadIdx.x; i < n; i += 1024) {
     const int o = (int)(i / K), k = (int)(i - (long)o * K);
-    dworig[i] = (dweff[i] - coef * u[o] * v[k]) / sg;
+    dworig[i] = dweff[i] / sg - coef * u[o] * v[k];
   }
 }
 

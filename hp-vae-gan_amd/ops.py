@@ -14,6 +14,31 @@ from . import lib
 from .lib import call, ptr, stream
 
 _ws_cache = {}
+_kernel_timer = None
+
+
+class KernelTimer:
+    """Brackets matching conv launches with HIP events recorded on the launch stream (torch's current stream is the
+    stream every kernel of this package is enqueued on), so bench.py can report the dominant kernel's average
+    duration measured live inside its timed region."""
+
+    def __init__(self, match):
+        self.match = match
+        self.events = []
+
+    def summary(self):
+        """{(B, Cin, T, H, W): (average ms, launches)} - call after a device synchronise."""
+        acc = {}
+        for key, e0, e1 in self.events:
+            ms = e0.elapsed_time(e1)
+            tot, n = acc.get(key, (0.0, 0))
+            acc[key] = (tot + ms, n + 1)
+        return {k: (tot / n, n) for k, (tot, n) in acc.items()}
+
+
+def set_kernel_timer(t):
+    global _kernel_timer
+    _kernel_timer = t
 
 
 def workspace(nbytes, device):
@@ -81,8 +106,15 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     sc = sh = None
     if in_affine is not None:
         sc, sh = in_affine
+    timed = None
+    if _kernel_timer is not None and _kernel_timer.match({"Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip}):
+        timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        timed[0].record()
     call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
          1 if out_lrelu else 0, B, cin_k, cout_k, T, H, W, KT, stream())
+    if timed is not None:
+        timed[1].record()
+        _kernel_timer.events.append(((B, cin_k, T, H, W), timed[0], timed[1]))
     return y
 
 

@@ -1,0 +1,91 @@
+"""Flat parameter / gradient arenas, Adam and gradient clipping on the gfx950 kernels.
+
+Replaces, for the hot path, optim.Adam(parameter_list, betas=(beta1, 0.999)) (train_video.py:55,88) and
+torch.nn.utils.clip_grad_norm_(G.parameters(), grad_clip) (train_video.py:201).  All parameters of a module live in
+ONE contiguous fp32 buffer (and their gradients in a second one), so the global L2 norm is a single reduction and
+an Adam step is one launch per parameter group instead of one per tensor."""
+import torch
+
+from . import ops
+
+_ALIGN = 64  # floats: every parameter starts on a 256-byte boundary
+
+
+class ParamArena:
+    """Re-homes every parameter of `module` into one flat buffer and pre-binds .grad to views of a flat gradient
+    buffer (autograd then accumulates in place).  Build it after .to(device) / init_next_stage(); values are kept."""
+
+    def __init__(self, module):
+        params = list(module.parameters())
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.range = {}
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                n = p.numel()
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+                self.range[id(p)] = (o, n)
+        self.params = params
+        self.total = total
+
+    def span(self, params):
+        """[lo, hi) flat range covering `params` (they must be contiguous in the arena)."""
+        rs = sorted(self.range[id(p)] for p in params)
+        lo = rs[0][0]
+        hi = rs[-1][0] + (rs[-1][1] + _ALIGN - 1) // _ALIGN * _ALIGN
+        covered = sum((n + _ALIGN - 1) // _ALIGN * _ALIGN for _, n in rs)
+        if covered != hi - lo:
+            raise ValueError("parameter group is not contiguous in the arena")
+        return lo, hi
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:  # re-bind in case autograd replaced a .grad tensor
+            o, n = self.range[id(p)]
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def clip_grad_norm_(self, max_norm, info=None):
+        """g *= min(1, max_norm / (||g||_2 + 1e-6)) over the whole arena; `info` (2 floats) receives (coef, norm)."""
+        sq = ops.sqsum(self.grad)
+        ops.clip_scale_(self.grad, sq, max_norm, info)
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (eps 1e-8, no weight decay, no amsgrad) over arena ranges, one lr per group."""
+
+    def __init__(self, arena, groups, betas=(0.5, 0.999), eps=1e-8):
+        """groups: list of (iterable of parameters, lr)."""
+        self.arena = arena
+        self.betas = betas
+        self.eps = eps
+        self.groups = []
+        for params, lr in groups:
+            params = list(params)
+            if not params:
+                continue
+            lo, hi = arena.span(params)
+            self.groups.append({"lo": lo, "hi": hi, "lr": lr,
+                                "m": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device),
+                                "v": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device)})
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        for g in self.groups:
+            lo, hi = g["lo"], g["hi"]
+            ops.adam_step_(self.arena.flat[lo:hi], self.arena.grad[lo:hi], g["m"], g["v"], g["lr"], self.betas[0], self.betas[1],
+                           self.eps, self.t)
+
+    def state_dict(self):
+        return {"t": self.t, "groups": [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in g.items()} for g in self.groups]}

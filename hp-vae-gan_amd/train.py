@@ -1,0 +1,164 @@
+"""Per-scale trainer: the hot loop of the reference's train(opt, netG) (train_video.py:25-258, train_image.py:39-272)
+on the MI355X kernels.  Same `opt` blackboard fields, same step sequence and the same quirks (SURVEY.md 3.1 a-j):
+netG stays in train mode for every forward, noise amplitude calibrated at iteration 0 and divided by batch_size,
+clip over ALL generator gradients, a fresh Adam per stage, D gradients of the G step discarded.
+
+Data loading, logging, tensorboard and checkpoint writing are out of scope: `data` is any iterable
+yielding `real` (stage 0) or `(real, real_zero)` device tensors."""
+import itertools
+
+import torch
+
+from . import ops
+from . import optim as hp_optim
+from . import utils
+from .modules import networks_2d, networks_3d
+from .modules.losses import kl_criterion, mse_loss, wgan_mean
+from .modules.utils import calc_gradient_penalty
+
+
+def _networks(opt):
+    return networks_3d if getattr(opt, 'dims', 3) == 3 else networks_2d
+
+
+def generator_param_groups(opt, netG):
+    """Adam parameter groups and learning rates of the generator for stage opt.scale_idx (train_video.py:57-86)."""
+    groups = []
+    body = netG.body
+    if not opt.train_all:
+        if opt.vae_levels < opt.scale_idx + 1:
+            depth = min(opt.train_depth, len(body) - opt.vae_levels + 1)
+            blocks = list(body[-depth:])
+            groups += [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, b in enumerate(blocks)]
+        else:
+            lr0 = opt.lr_g * (opt.lr_scale ** opt.scale_idx)
+            groups += [(netG.encode.parameters(), lr0), (netG.decoder.parameters(), lr0)]
+            blocks = list(body[-opt.train_depth:])
+            groups += [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, b in enumerate(blocks)]
+    else:
+        if len(body) < opt.train_depth:
+            lr0 = opt.lr_g * (opt.lr_scale ** opt.scale_idx)
+            groups += [(netG.encode.parameters(), lr0), (netG.decoder.parameters(), lr0)]
+            groups += [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(body) - 1 - i))) for i, b in enumerate(body)]
+        else:
+            blocks = list(body[-opt.train_depth:])
+            groups += [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, b in enumerate(blocks)]
+    return groups
+
+
+class StageTrainer:
+    """State of one pyramid stage: discriminator, arenas and optimisers (train_video.py:38-96), plus `step()` =
+    one iteration of the hot loop (train_video.py:111-202)."""
+
+    def __init__(self, opt, netG, netD=None):
+        self.opt = opt
+        self.netG = netG
+        self.dims = getattr(opt, 'dims', 3)
+        nets = _networks(opt)
+        self.is_gan = opt.vae_levels < opt.scale_idx + 1
+        self.netD = None
+        if self.is_gan:
+            self.netD = netD if netD is not None else getattr(nets, opt.discriminator)(opt).to(opt.device)
+            self.arenaD = hp_optim.ParamArena(self.netD)
+            self.optimizerD = hp_optim.FlatAdam(self.arenaD, [(self.netD.parameters(), opt.lr_d)], betas=(opt.beta1, 0.999))
+        self.arenaG = hp_optim.ParamArena(netG)
+        self.optimizerG = hp_optim.FlatAdam(self.arenaG, generator_param_groups(opt, netG), betas=(opt.beta1, 0.999))
+        level0 = utils.images.level_shape_3d(0, opt) if self.dims == 3 else utils.images.level_shape_2d(0, opt)
+        # latent size = the scale-0 size (train_video.py:39-42: set once at stage 0; train_image.py:137-139: every iteration)
+        opt.Z_init_size = [opt.batch_size, opt.latent_dim, *level0]
+        self.iteration = 0
+        self.clip_info = torch.zeros(2, dtype=torch.float32, device=opt.device)
+        self.last = {}
+
+    def calibrate_noise_amp(self, real, real_zero):
+        """Iteration-0 noise amplitude (train_video.py:131-145)."""
+        opt = self.opt
+        if opt.const_amp:
+            opt.Noise_Amps.append(1)
+            return
+        with torch.no_grad():
+            if opt.scale_idx == 0:
+                opt.noise_amp = 1
+                opt.Noise_Amps.append(opt.noise_amp)
+            else:
+                opt.Noise_Amps.append(0)
+                z_reconstruction, _, _ = self.netG(real_zero, opt.Noise_Amps, mode="rec")
+                rmse = torch.sqrt(mse_loss(real, z_reconstruction))
+                opt.noise_amp = opt.noise_amp_init * rmse.item() / opt.batch_size
+                opt.Noise_Amps[-1] = opt.noise_amp
+
+    def step(self, real, real_zero, noise_init=None, alpha=None):
+        """One training iteration.  `noise_init` / `alpha` may be injected (parity tests); otherwise drawn like the
+        reference does (utils.generate_noise on the device; torch.rand(1,1) on the CPU generator)."""
+        opt, netG = self.opt, self.netG
+        if noise_init is None:
+            noise_init = utils.generate_noise(size=opt.Z_init_size, device=opt.device)
+        if self.iteration == 0:
+            self.calibrate_noise_amp(real, real_zero)
+
+        out = {}
+        generated, generated_vae, (mu, logvar) = netG(real_zero, opt.Noise_Amps, mode="rec")
+        if not self.is_gan:
+            rec_vae_loss = mse_loss(generated, real) + mse_loss(generated_vae, real_zero)
+            kl_loss = kl_criterion(mu, logvar)
+            total_loss = opt.rec_weight * rec_vae_loss + opt.kl_weight * kl_loss
+            out.update(rec_vae_loss=rec_vae_loss.detach(), kl_loss=kl_loss.detach())
+        else:
+            netD = self.netD
+            self.arenaD.zero_grad()
+            errD_real = wgan_mean(netD(real), -1.0)
+            fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
+            errD_fake = wgan_mean(netD(fake.detach()), 1.0)
+            gradient_penalty = calc_gradient_penalty(netD, real, fake, opt.lambda_grad, opt.device, alpha=alpha)
+            errD_total = errD_real + errD_fake + gradient_penalty
+            errD_total.backward()
+            if getattr(opt, 'record_grads', False):
+                out['gradD_flat'] = self.arenaD.grad.clone()
+            self.optimizerD.step()
+
+            rec_loss = mse_loss(generated, real)
+            # D's own weight gradients of this pass are discarded by the reference (D.zero_grad() next iteration);
+            # freezing D here skips that wasted work without changing any result
+            for p in netD.parameters():
+                p.requires_grad_(False)
+            errG = wgan_mean(netD(fake), -1.0) * opt.disc_loss_weight
+            for p in netD.parameters():
+                p.requires_grad_(True)
+            total_loss = opt.rec_weight * rec_loss + errG
+            out.update(errD_real=errD_real.detach(), errD_fake=errD_fake.detach(), gradient_penalty=gradient_penalty.detach(),
+                       rec_loss=rec_loss.detach(), errG=errG.detach(), fake=fake.detach())
+
+        self.arenaG.zero_grad()
+        total_loss.backward()
+        if getattr(opt, 'record_grads', False):
+            out['gradG_flat'] = self.arenaG.grad.clone()
+        self.arenaG.clip_grad_norm_(opt.grad_clip, self.clip_info)
+        self.optimizerG.step()
+        self.iteration += 1
+        out.update(total_loss=total_loss.detach(), generated=generated.detach(), generated_vae=generated_vae.detach(),
+                   mu=mu.detach(), logvar=logvar.detach(), clip_info=self.clip_info)
+        self.last = out
+        return out
+
+
+def train(opt, netG, data, netD=None, niter=None):
+    """Train stage opt.scale_idx for opt.niter iterations (reference: train(opt, netG)).  Returns the StageTrainer
+    (holding netD and the last losses) so that the caller can checkpoint exactly what the reference saves."""
+    if getattr(opt, 'dims', 3) == 3:
+        fps, td, fps_index = utils.get_fps_td_by_index(opt.scale_idx, opt)
+        opt.fps, opt.td, opt.fps_index = fps, td, fps_index
+    trainer = StageTrainer(opt, netG, netD)
+    iterator = iter(data)
+    for _ in range(opt.niter if niter is None else niter):
+        try:
+            item = next(iterator)
+        except StopIteration:
+            iterator = iter(data)
+            item = next(iterator)
+        if opt.scale_idx > 0:
+            real, real_zero = item
+        else:
+            real = item
+            real_zero = real
+        trainer.step(real, real_zero)
+    return trainer

@@ -1,0 +1,302 @@
+"""GPU parity tests: every HIP op (called through the C ABI via hp_vae_gan_amd.ops) against the CPU oracle on the
+same seeded inputs, plus the reference-generated golden block fixtures.  Tolerance 1e-3 relative (north_star);
+fp32 MFMA == fmaf chain, so the observed error is ~1e-6."""
+import pytest
+import torch
+
+from helpers import RTOL, assert_close, bn_bias_atol, load_golden, opt_from
+from oracle import hpvg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import hp_vae_gan_amd as hp  # noqa: F401
+    from hp_vae_gan_amd import ops as _ops
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, spatial)
+    (2, 3, 64, (5, 7, 9)), (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (2, 64, 3, (3, 6, 5)), (2, 64, 1, (2, 5, 7)),
+    (1, 128, 64, (2, 4, 5)), (1, 64, 128, (2, 5, 4)), (1, 8, 8, (1, 1, 1)), (1, 16, 24, (3, 4, 7)), (2, 3, 8, (4, 23, 41)),
+    (1, 64, 64, (5, 36, 65)), (1, 64, 64, (2, 9, 130)), (1, 5, 70, (2, 3, 300)),
+    (2, 3, 64, (11, 13)), (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 3, (30, 41)), (1, 64, 1, (7, 12)),
+    (1, 128, 64, (6, 5)), (1, 64, 128, (48, 65)), (1, 64, 64, (96, 129)),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,sp", CONV_CASES)
+def test_conv_fwd_bwd(ops, B, Cin, Cout, sp):
+    nd = len(sp)
+    x = _rand(B, Cin, *sp, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, *([3] * nd), seed=2, scale=0.1).requires_grad_(True)
+    b = _rand(Cout, seed=3).requires_grad_(True)
+    gy = _rand(B, Cout, *sp, seed=4)
+    y = O.conv(x, w, b)
+    dx, dw, db = torch.autograd.grad(y, [x, w, b], gy)
+
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    yd = ops.Conv.apply(xd, wd, bd, False)
+    assert_close(yd, y, RTOL, "conv.y")
+    dxd, dwd, dbd = torch.autograd.grad(yd, [xd, wd, bd], gy.to(DEV))
+    assert_close(dxd, dx, RTOL, "conv.dx")
+    assert_close(dwd, dw, RTOL, "conv.dw")
+    assert_close(dbd, db, RTOL, "conv.db")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
+def test_conv_lrelu_epilogue_and_affine_prologue(ops, B, Cin, Cout, sp):
+    nd = len(sp)
+    x = _rand(B, Cin, *sp, seed=5)
+    w = _rand(Cout, Cin, *([3] * nd), seed=6, scale=0.1)
+    b = _rand(Cout, seed=7)
+    sc, sh = _rand(Cin, seed=8).abs() + 0.5, _rand(Cin, seed=9)
+    shape = (1, -1) + (1,) * nd
+    want = O.leaky_relu(O.conv(O.leaky_relu(x * sc.view(shape) + sh.view(shape)), w, b))
+    got = ops.conv_fwd_raw(x.to(DEV), w.to(DEV), b.to(DEV), out_lrelu=True, in_affine=(sc.to(DEV), sh.to(DEV)), in_lrelu=True)
+    assert_close(got, want, RTOL, "conv.fused")
+    want2 = O.conv(x * sc.view(shape) + sh.view(shape), w, None)
+    got2 = ops.conv_fwd_raw(x.to(DEV), w.to(DEV), None, in_affine=(sc.to(DEV), sh.to(DEV)), in_lrelu=False)
+    assert_close(got2, want2, RTOL, "conv.affine_only")
+
+
+def test_conv_double_backward_closed_set(ops):
+    """d/dw and d/dx of <conv_bwd_data(dy, w), g> and of <conv_bwd_weight(dy, x), gw> against torch autograd."""
+    x = _rand(2, 8, 3, 5, 6, seed=10).requires_grad_(True)
+    w = _rand(12, 8, 3, 3, 3, seed=11, scale=0.2).requires_grad_(True)
+    gy = _rand(2, 12, 3, 5, 6, seed=12).requires_grad_(True)
+    y = O.conv(x, w)
+    dx, dw = torch.autograd.grad(y, [x, w], gy, create_graph=True)
+    loss = (dx ** 2).sum() + (dw ** 3).sum()
+    want = torch.autograd.grad(loss, [x, w, gy])
+
+    xd, wd, gyd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, gy))
+    yd = ops.Conv.apply(xd, wd, None, False)
+    dxd, dwd = torch.autograd.grad(yd, [xd, wd], gyd, create_graph=True)
+    assert_close(dxd, dx, RTOL, "dx")
+    assert_close(dwd, dw, RTOL, "dw")
+    lossd = (dxd ** 2).sum() + (dwd ** 3).sum()
+    got = torch.autograd.grad(lossd, [xd, wd, gyd])
+    for g, r, n in zip(got, want, ("d/dx", "d/dw", "d/dgy")):
+        assert_close(g, r, RTOL, "double." + n)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 3, 5, 7), (2, 64, 4, 18, 33), (1, 16, 37, 41), (2, 64, 1, 1, 3)])
+def test_bn_act(ops, shape):
+    C = shape[1]
+    r = (_rand(*shape, seed=20) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (_rand(C, seed=21).abs() + 0.5).requires_grad_(True)
+    beta = _rand(C, seed=22).requires_grad_(True)
+    rm, rv = _rand(C, seed=23), _rand(C, seed=24).abs() + 0.5
+    gh = _rand(*shape, seed=25)
+    rm_o, rv_o = rm.clone(), rv.clone()
+    h = O.leaky_relu(O.batch_norm_train(r, gamma, beta, rm_o, rv_o))
+    dr, dg, db = torch.autograd.grad(h, [r, gamma, beta], gh)
+
+    rd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (r, gamma, beta))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    hd = ops.BNAct.apply(rd, gd, bd, rmd, rvd, 0.1, 1e-5, True)
+    assert_close(hd, h, RTOL, "bn.h")
+    assert_close(rmd, rm_o, RTOL, "bn.running_mean")
+    assert_close(rvd, rv_o, RTOL, "bn.running_var")
+    drd, dgd, dbd = torch.autograd.grad(hd, [rd, gd, bd], gh.to(DEV))
+    assert_close(drd, dr, RTOL, "bn.dr")
+    assert_close(dgd, dg, RTOL, "bn.dgamma")
+    assert_close(dbd, db, RTOL, "bn.dbeta")
+
+
+@pytest.mark.parametrize("Co,Ci,nd", [(64, 3, 3), (64, 64, 3), (24, 16, 3), (64, 64, 2), (1, 64, 3)])
+def test_spectral_norm_weight(ops, Co, Ci, nd):
+    w = _rand(Co, Ci, *([3] * nd), seed=30, scale=0.1).requires_grad_(True)
+    u = torch.nn.functional.normalize(_rand(Co, seed=31), dim=0)
+    v = torch.nn.functional.normalize(_rand(Ci * 3 ** nd, seed=32), dim=0)
+    gw = _rand(*w.shape, seed=33)
+    uo, vo = u.clone(), v.clone()
+    we = O.spectral_norm_weight(w, uo, vo, True)
+    (dw,) = torch.autograd.grad(we, w, gw)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    ud, vd = u.to(DEV), v.to(DEV)
+    wed = ops.SpectralNormWeight.apply(wd, ud, vd, True, 1e-12)
+    assert_close(wed, we, RTOL, "sn.w")
+    assert_close(ud, uo, RTOL, "sn.u")
+    assert_close(vd, vo, RTOL, "sn.v")
+    (dwd,) = torch.autograd.grad(wed, wd, gw.to(DEV))
+    assert_close(dwd, dw, RTOL, "sn.dw")
+    # eval mode: no power iteration
+    we2 = O.spectral_norm_weight(w, uo, vo, False)
+    wed2 = ops.SpectralNormWeight.apply(wd, ud, vd, False, 1e-12)
+    assert_close(wed2, we2, RTOL, "sn.w.eval")
+
+
+@pytest.mark.parametrize("in_shape,size", [((2, 3, 4, 18, 33), (4, 23, 41)), ((1, 3, 5, 57, 102), (7, 72, 129)),
+                                           ((2, 3, 7, 20, 31), (13, 29, 40)), ((2, 3, 24, 33), (30, 41)), ((1, 2, 1, 5, 5), (1, 9, 3)),
+                                           ((1, 1, 3, 4, 5), (1, 1, 1))])
+def test_upsample(ops, in_shape, size):
+    x = _rand(*in_shape, seed=40).requires_grad_(True)
+    y = O.resize_linear_ac(x, size)
+    gy = _rand(*y.shape, seed=41)
+    (dx,) = torch.autograd.grad(y, x, gy, retain_graph=True)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    yd = ops.UpsampleAC.apply(xd, tuple(size), None, 0.0)
+    assert_close(yd, y, RTOL, "up.y")
+    (dxd,) = torch.autograd.grad(yd, xd, gy.to(DEV))
+    assert_close(dxd, dx, RTOL, "up.dx")
+    noise = _rand(*y.shape, seed=42)
+    yd1, ydn = ops.UpsampleAC.apply(xd, tuple(size), noise.to(DEV), 0.37)
+    assert_close(yd1, y, RTOL, "up.y(noisy call)")
+    assert_close(ydn, y + 0.37 * noise, RTOL, "up.yn")
+    g2 = _rand(*y.shape, seed=43)
+    (dxd2,) = torch.autograd.grad([yd1, ydn], xd, [gy.to(DEV), g2.to(DEV)])
+    (dx2,) = torch.autograd.grad(y, x, gy + g2)
+    assert_close(dxd2, dx2, RTOL, "up.dx(two outputs)")
+
+
+def test_pointwise_and_losses(ops):
+    a = _rand(2, 3, 5, 17, 19, seed=50).requires_grad_(True)
+    b = _rand(2, 3, 5, 17, 19, seed=51).requires_grad_(True)
+    g = _rand(2, 3, 5, 17, 19, seed=52)
+    ad, bd = (t.detach().to(DEV).requires_grad_(True) for t in (a, b))
+    # tanh(x + res)
+    y = torch.tanh(a + b)
+    da, db = torch.autograd.grad(y, [a, b], g)
+    yd = ops.TanhRes.apply(ad, bd)
+    dad, dbd = torch.autograd.grad(yd, [ad, bd], g.to(DEV))
+    assert_close(yd, y, RTOL, "tanhres.y"); assert_close(dad, da, RTOL, "tanhres.da"); assert_close(dbd, db, RTOL, "tanhres.db")
+    y = torch.tanh(a)
+    (da,) = torch.autograd.grad(y, a, g)
+    yd = ops.TanhRes.apply(ad, None)
+    (dad,) = torch.autograd.grad(yd, ad, g.to(DEV))
+    assert_close(yd, y, RTOL, "tanh.y"); assert_close(dad, da, RTOL, "tanh.da")
+    # mse
+    m = O.mse(a, b)
+    da, db = torch.autograd.grad(m, [a, b])
+    md = ops.MSE.apply(ad, bd)
+    dad, dbd = torch.autograd.grad(md, [ad, bd])
+    assert_close(md, m, RTOL, "mse"); assert_close(dad, da, RTOL, "mse.da"); assert_close(dbd, db, RTOL, "mse.db")
+    # signed mean
+    m = -a.mean() * 1.0
+    (da,) = torch.autograd.grad(m, a)
+    md = ops.MeanScaled.apply(ad, -1.0)
+    (dad,) = torch.autograd.grad(md, ad)
+    assert_close(md, m, RTOL, "mean"); assert_close(dad, da, RTOL, "mean.da")
+    # KL + reparameterize
+    mu = _rand(2, 128, 4, 18, 33, seed=53).requires_grad_(True)
+    lv = (_rand(2, 128, 4, 18, 33, seed=54) * 0.3).requires_grad_(True)
+    eps = _rand(2, 128, 4, 18, 33, seed=55)
+    gz = _rand(2, 128, 4, 18, 33, seed=56)
+    mud, lvd = (t.detach().to(DEV).requires_grad_(True) for t in (mu, lv))
+    kl = O.kl_criterion(mu, lv)
+    dmu, dlv = torch.autograd.grad(kl, [mu, lv])
+    kld = ops.KL.apply(mud, lvd)
+    dmud, dlvd = torch.autograd.grad(kld, [mud, lvd])
+    assert_close(kld, kl, RTOL, "kl"); assert_close(dmud, dmu, RTOL, "kl.dmu"); assert_close(dlvd, dlv, RTOL, "kl.dlv")
+    z = eps * torch.exp(0.5 * lv) + mu
+    dmu, dlv = torch.autograd.grad(z, [mu, lv], gz)
+    zd = ops.Reparam.apply(mud, lvd, eps.to(DEV))
+    dmud, dlvd = torch.autograd.grad(zd, [mud, lvd], gz.to(DEV))
+    assert_close(zd, z, RTOL, "reparam.z"); assert_close(dmud, dmu, RTOL, "reparam.dmu"); assert_close(dlvd, dlv, RTOL, "reparam.dlv")
+    # gradient-penalty norm term and lerp
+    gg = _rand(2, 3, 5, 17, 19, seed=57).requires_grad_(True)
+    gp = ((gg.norm(2, dim=1) - 1) ** 2).mean() * 0.1
+    (dgg,) = torch.autograd.grad(gp, gg)
+    ggd = gg.detach().to(DEV).requires_grad_(True)
+    gpd = ops.GradPenalty.apply(ggd, 0.1)
+    (dggd,) = torch.autograd.grad(gpd, ggd)
+    assert_close(gpd, gp, RTOL, "gp"); assert_close(dggd, dgg, RTOL, "gp.dg")
+    al = torch.tensor([0.3125])
+    assert_close(ops.lerp(ad, bd, al.to(DEV)), 0.3125 * a + (1 - 0.3125) * b, RTOL, "lerp")
+
+
+def test_adam_and_clip(ops):
+    n = 100003
+    p, g = _rand(n, seed=60), _rand(n, seed=61) * 3
+    total, coef = O.clip_grad_norm([g_ := g.clone()], 5.0)
+    gd = g.to(DEV)
+    info = torch.zeros(2, device=DEV)
+    ops.clip_scale_(gd, ops.sqsum(gd), 5.0, info)
+    assert_close(gd, g_, RTOL, "clip.g")
+    assert_close(info.cpu(), torch.stack([coef, total]), RTOL, "clip.info")
+    pd, md, vd = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    po, state = p.clone(), {}
+    for t in range(1, 4):
+        O.adam_step(po, g_ * t, state, 5e-4, 0.5)
+        ops.adam_step_(pd, (gd * t).contiguous(), md, vd, 5e-4, 0.5, 0.999, 1e-8, t)
+    assert_close(pd, po, 1e-5, "adam.p")
+    assert_close(md, state["m"], RTOL, "adam.m")
+    assert_close(vd, state["v"], RTOL, "adam.v")
+
+
+# ------------------------------------------------------------------------------------------------ golden block fixtures
+def _module_for(name):
+    from hp_vae_gan_amd.modules import networks_2d as n2, networks_3d as n3, _nets
+    cin_cout = [int(t) for t in name.split("_")[1:3]]
+    if name.startswith("convblock3dsn"):
+        return n3.ConvBlock3DSN(*cin_cout, 3, 1, 1)
+    if name.startswith("convblock2dsn"):
+        return n2.ConvBlock2DSN(*cin_cout, 3, 1, 1)
+    if name.startswith("convblock3d"):
+        return n3.ConvBlock3D(*cin_cout, 3, 1, 1, bn=not name.endswith("plain"), act=None if name.endswith("plain") else "lrelu")
+    if name.startswith("convblock2d"):
+        return n2.ConvBlock2D(*cin_cout, 3, 1, 1)
+    if name.startswith("tail3d"):
+        return _nets.Conv(3, *cin_cout)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["convblock3d_3_8", "convblock3d_64_64", "convblock3d_128_8", "convblock3d_8_128_plain",
+                                  "convblock3dsn_3_64", "convblock3dsn_16_24", "convblock2d_3_64", "convblock2d_64_64",
+                                  "convblock2dsn_64_64", "tail3d_64_3", "tail3d_64_1"])
+def test_golden_blocks(ops, name):
+    fx = load_golden("ops.pt")[name]
+    blk = _module_for(name)
+    blk.load_state_dict(fx["sd_before"])
+    blk.to(DEV)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    y = blk(x)
+    assert_close(y, fx["y"], RTOL, name + ".y")
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x] + list(params.values()), fx["gy"].to(DEV))
+    assert_close(grads[0], fx["dx"], RTOL, name + ".dx")
+    for (k, _), g in zip(params.items(), grads[1:]):
+        assert_close(g, fx["dparams"][k], RTOL, name + ".d" + k, atol=bn_bias_atol("blk." + k, {"blk." + kk: vv for kk, vv in fx["dparams"].items()}, 1e-6))
+    sd = blk.state_dict()
+    for k, v in fx["sd_after"].items():
+        assert_close(sd[k].float(), v.float(), RTOL, name + ".after." + k)
+
+
+def test_golden_gradient_penalty(ops):
+    """calc_gradient_penalty through WDiscriminator3D: value and the second-order gradients on every D parameter."""
+    from hp_vae_gan_amd.modules import networks_3d as n3
+    from hp_vae_gan_amd.modules.utils import calc_gradient_penalty
+    fx = load_golden("ops.pt")["gp3d"]
+    opt = opt_from(dict(fx["opt"]))
+    D = n3.WDiscriminator3D(opt)
+    D.load_state_dict(fx["D_before"])
+    D.to(DEV)
+    gp = calc_gradient_penalty(D, fx["real"].to(DEV), fx["fake"].to(DEV), 0.1, DEV, alpha=fx["alpha"])
+    assert_close(gp, fx["gp"], RTOL, "gp")
+    gp.backward()
+    for n, p in D.named_parameters():
+        ref = fx["grads"][n]
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-9, n
+        else:
+            assert_close(p.grad, ref, RTOL, "gp.grad." + n)
+    sd = D.state_dict()
+    for k, v in fx["D_after"].items():
+        if k.endswith(("weight_u", "weight_v")):
+            assert_close(sd[k], v, RTOL, "gp.after." + k)
+
+
+def test_cpu_tensor_fails_loudly(ops):
+    with pytest.raises(RuntimeError):
+        ops.Conv.apply(torch.zeros(1, 3, 4, 4), torch.zeros(8, 3, 3, 3), None, False)

@@ -1,0 +1,122 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol of include/hpvg.h, the pyramid
+tables of the product package equal the reference's (golden tables.json), module trees / state_dict layouts accept
+the reference's state_dicts, Adam parameter groups follow train_video.py:57-86, and compute on CPU fails loudly."""
+import ctypes
+import json
+import os
+
+import pytest
+import torch
+
+import hp_vae_gan_amd as hp
+from hp_vae_gan_amd import lib as hplib
+from hp_vae_gan_amd import train as hp_train
+from hp_vae_gan_amd import utils as hu
+from hp_vae_gan_amd.modules import networks_2d, networks_3d
+from helpers import GOLDEN, load_golden, opt_from
+from oracle import hpvg_oracle as O
+
+
+def test_library_loads_and_exports_header_symbols():
+    declared = hplib.check_symbols()
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(hplib.LIB_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_size_queries_and_plans_run_without_gpu():
+    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 3) == (8 * 27 + 2) * 2 * 64 * 4
+    assert hplib.call("hpvg_conv_wpack_floats", 3, 64, 3) == (1 * 27 + 2) * 2 * 64 * 2
+    out = (ctypes.c_int * 10)()
+    for (B, Ci, Co, T, H, W, KT) in [(2, 64, 64, 13, 144, 256, 3), (2, 64, 64, 4, 18, 33, 3), (2, 3, 64, 1, 192, 256, 1), (2, 64, 3, 7, 91, 162, 3)]:
+        assert hplib.call("hpvg_conv_fwd_plan", B, Ci, Co, T, H, W, KT, out) == 0
+        Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds, ntiles = list(out)
+        assert Th >= 1 and Tw >= 1 and nth * Th >= H and ntw * Tw >= W and nblocks <= 4 * NB and lds <= 160 * 1024
+        assert ntiles == B * T * nth * ntw
+        assert hplib.call("hpvg_conv_bwd_weight_plan", B, Ci, Co, T, H, W, KT, out) == 0
+        assert out[0] >= 1 and out[8] <= 80 * 1024 and out[5] >= 1
+        assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT) > 0
+    with pytest.raises(RuntimeError, match="HPVG_ERR_ARG"):  # bad KT -> error code, not a crash
+        hplib.call("hpvg_conv_fwd_plan", 1, 1, 1, 1, 1, 1, 2, out)
+
+
+def test_tables_match_reference():
+    rows = json.load(open(os.path.join(GOLDEN, "tables.json")))
+    for row in rows:
+        opt = opt_from(dict(min_size=row["min_size"], max_size=row["max_size"], img_size=row["img_size"], ar=row["ar"],
+                            scale_factor_init=0.75, sampling_rates=[4, 3, 2, 1], fps_lcm=12, org_fps=24))
+        hu.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        assert (opt.num_scales, opt.stop_scale, opt.scale1, opt.scale_factor) == (row["num_scales"], row["stop_scale"], row["scale1"], row["scale_factor"])
+        for lv in row["levels"]:
+            i = lv["index"]
+            assert hu.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size) == lv["w"]
+            fps, td, fi = hu.get_fps_td_by_index(i, opt)
+            assert (fps, td, fi) == (lv["fps"], lv["td"], lv["fps_index"])
+            assert hu.images.level_shape_3d(i, opt) == [lv["td"], lv["h"], lv["w"]]
+            assert hu.images.level_shape_2d(i, opt) == [lv["h"], lv["w"]]
+
+
+@pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step2d_gan_s2.pt"])
+def test_state_dict_layout_is_the_references(fname):
+    fx = load_golden(fname)
+    dims, s = fx["dims"], fx["scale_idx"]
+    nets = networks_3d if dims == 3 else networks_2d
+    opt = opt_from(fx["opt"])
+    G = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(s):
+        G.init_next_stage()
+    assert list(G.state_dict().keys()) == list(fx["G_init"].keys())
+    G.load_state_dict(fx["G_init"], strict=True)
+    D = (nets.WDiscriminator3D if dims == 3 else nets.WDiscriminator2D)(opt)
+    assert list(D.state_dict().keys()) == list(fx["D_init"].keys())
+    D.load_state_dict(fx["D_init"], strict=True)
+    assert [n for n, _ in G.named_parameters()] == [k for k in fx["G_init"] if O.is_param(k)]
+    for k, v in fx["G_init"].items():
+        assert G.state_dict()[k].shape == v.shape and G.state_dict()[k].dtype == v.dtype
+
+
+def test_seeded_construction_consumes_rng_like_reference():
+    """Same torch initialisers in the same order: a seeded build reproduces the fixture-independent init statistics."""
+    opt = opt_from(dict(nc_im=3, nfc=8, latent_dim=8, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, vae_levels=2, train_all=False))
+    torch.manual_seed(3)
+    a = networks_3d.GeneratorHPVAEGAN(opt)
+    torch.manual_seed(3)
+    b = networks_3d.GeneratorHPVAEGAN(opt)
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+    w = a.decoder.head.conv.weight
+    bound = 1 / (8 * 27) ** 0.5
+    assert float(w.abs().max()) <= bound + 1e-6 and float(a.decoder.head.norm.weight.min()) == 1.0
+    u = a.encode.features.conv_block_0.conv.weight_u
+    assert abs(float(u.norm()) - 1.0) < 1e-5
+
+
+def test_param_groups_follow_reference_rules():
+    base = dict(nc_im=3, nfc=8, latent_dim=8, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, lr_g=5e-4, lr_scale=0.2, train_depth=1)
+    for vae_levels, scale_idx, train_all in [(3, 0, False), (3, 2, False), (3, 3, False), (3, 5, False), (1, 1, False), (3, 1, True), (3, 4, True)]:
+        opt = opt_from(dict(base, vae_levels=vae_levels, scale_idx=scale_idx, train_all=train_all))
+        G = networks_3d.GeneratorHPVAEGAN(opt)
+        for _ in range(scale_idx):
+            G.init_next_stage()
+        groups = hp_train.generator_param_groups(opt, G)
+        got = []
+        names = {id(p): n for n, p in G.named_parameters()}
+        for params, lr in groups:
+            ps = list(params)
+            prefix = os.path.commonprefix([names[id(p)] for p in ps])
+            got.append((prefix.split(".")[0] + ("." + prefix.split(".")[1] if prefix.startswith("body") else ""), lr))
+        PG = {k: v for k, v in G.state_dict().items()}
+        want = [(p.rstrip("."), lr) for p, lr in O.g_param_groups(PG, opt, scale_idx)]
+        assert [(a, pytest.approx(b)) for a, b in got] == want
+
+
+def test_compute_on_cpu_fails_loudly():
+    from hp_vae_gan_amd import ops
+    opt = opt_from(dict(nc_im=3, nfc=8, latent_dim=8, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, vae_levels=2, train_all=False))
+    D = networks_3d.WDiscriminator3D(opt)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D(torch.zeros(1, 3, 2, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.MSE.apply(torch.zeros(4), torch.zeros(4))

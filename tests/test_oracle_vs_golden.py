@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from helpers import GOLDEN, assert_close, load_golden, opt_from, oracle_state
+from helpers import GOLDEN, assert_close, bn_bias_atol, load_golden, opt_from, oracle_state
 from oracle import hpvg_oracle as O
 
 TIGHT = 2e-5
@@ -121,13 +121,6 @@ def test_gradient_penalty_second_order():
     for k, v in fx["D_after"].items():
         if k.endswith(("weight_u", "weight_v")):
             assert_close(PD[k], v, TIGHT, "gp.after." + k)
-
-
-def bn_bias_atol(k, grads):
-    """Absolute slack for conv biases that feed a BatchNorm (true gradient exactly 0, see test_blocks)."""
-    if k.endswith(".conv.bias") and (k[:-len("conv.bias")] + "norm.weight") in grads:
-        return 1e-4 * float(grads[k[:-len("bias")] + "weight"].abs().max())
-    return 1e-7
 
 
 def _run_stage(fname):
