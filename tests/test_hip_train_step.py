@@ -12,28 +12,33 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt"])
 def test_train_step_matches_reference(fname):
     fx = load_golden(fname)
+    gan = fx["D_init"] is not None
+    # quantities computed AFTER an optimizer step (GAN stage: errG and the G gradients go through the just-updated D;
+    # any iteration > 0) inherit Adam's +-lr sign-flip sensitivity: 3e-3 there, 1e-3 elsewhere
     for it, (rec, out, netG, netD, trainer) in enumerate(run_hip_stage(fx)):
+        post = 3e-3 if (gan or it > 0) else RTOL
         assert trainer.opt.Noise_Amps == pytest.approx(rec["noise_amps"], rel=1e-4)
         for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG"):
             if k in rec:
-                assert_close(out[k], rec[k], RTOL, "%s[%d].%s" % (fname, it, k))
+                tol = post if (k in ("errG", "total_loss") or it > 0) else RTOL
+                assert_close(out[k], rec[k], tol, "%s[%d].%s" % (fname, it, k))
         for k in ("generated", "generated_vae", "mu", "logvar", "fake"):
             if k in rec and k in out:
-                assert_close(out[k], rec[k], RTOL, "%s[%d].%s" % (fname, it, k))
+                assert_close(out[k], rec[k], RTOL if it == 0 else post, "%s[%d].%s" % (fname, it, k))
         gotG = flat_to_named(out["gradG_flat"], trainer.arenaG, netG)
         for k, g in rec["gradsG"].items():
             if g is None:
                 assert float(gotG[k].abs().max()) == 0.0, k
             else:
-                assert_close(gotG[k], g, RTOL, "%s[%d].gradG.%s" % (fname, it, k), atol=bn_bias_atol(k, rec["gradsG"], 1e-7))
-        assert_close(out["clip_info"][1], rec["total_norm"], RTOL, "%s[%d].total_norm" % (fname, it))
+                assert_close(gotG[k], g, post, "%s[%d].gradG.%s" % (fname, it, k), atol=bn_bias_atol(k, rec["gradsG"], 1e-7))
+        assert_close(out["clip_info"][1], rec["total_norm"], post, "%s[%d].total_norm" % (fname, it))
         if "gradsD" in rec:
             gotD = flat_to_named(out["gradD_flat"], trainer.arenaD, netD)
             for k, g in rec["gradsD"].items():
                 if g is None:
                     assert float(gotD[k].abs().max()) == 0.0, k
                 else:
-                    assert_close(gotD[k], g, RTOL, "%s[%d].gradD.%s" % (fname, it, k), atol=1e-7)
+                    assert_close(gotD[k], g, RTOL if it == 0 else post, "%s[%d].gradD.%s" % (fname, it, k), atol=1e-7)
         # post-step state: Adam moves a weight by ~lr*sign(g) (sign flips of ~0 gradients), so allow it+1 steps of lr
         lr = fx["opt"]["lr_g"] * (it + 1)
         sdG = netG.state_dict()
