@@ -174,23 +174,33 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* 
 }
 
 // per-channel sum over (b, spatial): out[c] = sum_b sum_s x[b][c][s]   (bias gradient)
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C,
-                                                           long S) {
+// two stages (grid (nsplit, C) partials in fp64, then one finishing thread per channel): reproducible, chip-filling
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int B, int C, long S, int nsplit,
+                                                                   double* __restrict__ part) {
   __shared__ double sh[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.y, k = blockIdx.x;
+  const long chunk = (S + nsplit - 1) / nsplit;
+  const long lo = (long)k * chunk, hi = (lo + chunk < S) ? lo + chunk : S;
   double acc = 0.0;
   for (int b = 0; b < B; ++b) {
     const float* p = x + ((long)b * C + c) * S;
     float loc = 0.f;
     int cnt = 0;
-    for (long i = threadIdx.x; i < S; i += 256) {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
       loc += p[i];
-      if (++cnt == 64) { acc += loc; loc = 0.f; cnt = 0; }
+      if (++cnt == 32) { acc += loc; loc = 0.f; cnt = 0; }
     }
     acc += loc;
   }
   const double tot = hpvg_block_sum_d(acc, sh);
-  if (threadIdx.x == 0) out[c] = (float)tot;
+  if (threadIdx.x == 0) part[(long)c * nsplit + k] = tot;
+}
+__global__ void channel_sum_finish_kernel(const double* __restrict__ part, int nsplit, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += part[(long)c * nsplit + k];
+  out[c] = (float)s;
 }
 
 struct WPlan {
@@ -277,10 +287,20 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   return hpvg_launch_status();
 }
 
-// out[c] = sum over batch and all spatial positions of x[b][c][...]  (conv bias gradient)
-int hpvg_channel_sum_f32(const float* x, float* out, int B, int C, long S, void* stream) {
-  if (!x || !out || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, S);
+// out[c] = sum over batch and all spatial positions of x[b][c][...]  (conv bias gradient); ws: C*64 doubles
+size_t hpvg_channel_sum_ws_bytes(int C) { return (size_t)C * 64 * sizeof(double); }
+int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!x || !out || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_channel_sum_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  long want = (1024 + C - 1) / C;
+  const long maxs = (S * B + 2047) / 2048;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  const int ns = (int)want;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, out);
   return hpvg_launch_status();
 }
 

@@ -34,7 +34,8 @@ _SIGS = {
     "hpvg_conv_bwd_weight_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],
-    "hpvg_channel_sum_f32": [P, P, I, I, L, P],
+    "hpvg_channel_sum_ws_bytes": [I],
+    "hpvg_channel_sum_f32": [P, P, P, Z, I, I, L, P],
     "hpvg_bn_ws_bytes": [I],
     "hpvg_bn_train_stats_f32": [P, P, P, P, P, F, F, P, P, P, P, P, Z, I, I, L, P],
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
@@ -63,7 +64,7 @@ _SIGS = {
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P],
 }
-_SIZE_FUNCS = {"hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
 
 
 def header_symbols():

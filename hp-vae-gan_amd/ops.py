@@ -138,7 +138,8 @@ def channel_sum_raw(dy):
     dy = _c(dy)
     B, C, T, H, W = geom(dy)
     out = torch.empty(C, dtype=torch.float32, device=dy.device)
-    call("hpvg_channel_sum_f32", ptr(dy), ptr(out), B, C, ctypes.c_long(T * H * W), stream())
+    ws = workspace(call("hpvg_channel_sum_ws_bytes", C), dy.device)
+    call("hpvg_channel_sum_f32", ptr(dy), ptr(out), ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(T * H * W), stream())
     return out
 
 

@@ -48,7 +48,8 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
                              int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient */
-int hpvg_channel_sum_f32(const float* x, float* out, int B, int C, long S, void* stream);
+size_t hpvg_channel_sum_ws_bytes(int C);
+int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
 
 /* ---- BatchNorm3d/2d, train mode on every forward (networks_3d.py:54), eps 1e-5, momentum 0.1 */
 size_t hpvg_bn_ws_bytes(int C);
