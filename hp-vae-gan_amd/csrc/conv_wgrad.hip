@@ -25,17 +25,19 @@ struct WgradArgs {
   const float* in_scale;
   const float* in_shift;
   float* part;
+  const float* zeros;  // >= 4 bytes of zeros in global memory (source of padding for the LDS-DMA staging)
   int B, Cin, Cout, T, H, W;
-  int Th, Tw, RS, DS, XS, QK, nth, ntw, ntiles, S, ncb, nob;
+  int Th, Tw, RS, DS, XS, QK, nth, ntw, S, ncb, nob;
   int in_lrelu;
 };
 
-template <int KT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* dys = lds;                 // [64][DS]
-  float* xsm = lds + 64 * a.DS;     // [64][XS]
 
+// Persistent, software-pipelined: one workgroup per CU (1 wave per SIMD), two LDS tile buffers; while the MFMA
+// K-loop of tile i runs out of buffer i&1, tile i+1 is register-staged into the other buffer in 8-channel batches
+// issued between K-loop segments (loads of batch b are in flight during segment b and written to LDS after it).
+template <int KT, int NJD, int NJX>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,9 +47,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int z = blockIdx.z;
   const int ob = z / a.ncb, cb = z % a.ncb;
   const int RS = a.RS, DS = a.DS, XS = a.XS;
+  const int BUF = 64 * (DS + XS);
   const long HW = (long)a.H * a.W;
+  const long cstride = (long)a.T * HW;
   const bool active = (ob * 64 + oblk * 32 < a.Cout) && (cb * 64 + cblk * 32 < a.Cin);
-  const bool prologue = a.in_scale != nullptr;
+  int no = a.Cout - ob * 64; if (no > 64) no = 64;   // channels present in this 64-block
+  int nc = a.Cin - cb * 64;  if (nc > 64) nc = 64;
+
+  // valid output time planes for this dt: the input plane t + dt - pt must exist
+  const int pt = (KT == 3 ? 1 : 0);
+  const int t_lo = (dt < pt) ? (pt - dt) : 0;
+  const int t_hi = (a.T - 1 + pt - dt < a.T - 1) ? (a.T - 1 + pt - dt) : (a.T - 1);
+  const int tv = t_hi - t_lo + 1;
+  const int ntiles = tv > 0 ? a.B * tv * a.nth * a.ntw : 0;
 
   f32x16 acc[9];
 #pragma unroll
@@ -55,83 +67,146 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+  // zero both buffers once: rows of absent channels are never written afterwards
+  for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
+
+  // ---- staging of the NEXT tile by LDS-DMA (global_load_lds_dword: no VGPR round trip, no ds_write pass).
+  // One wave instruction moves 64 consecutive positions of one channel row; lanes past the row end are masked
+  // off, out-of-image positions read a global zero word instead.  The DMA instructions are issued BETWEEN the
+  // MFMAs of the running K loop (one channel per 6 MFMAs), so they ride in the matrix pipe's shadow.
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // per-lane staging state: source pointer of the current channel row (or the zero word) and its per-channel byte
+  // stride (0 for padded positions), one pair per 256-position slot; lanes past the row end are masked off
+  const char* dptr[NJD];
+  const char* xptr[NJX];
+  unsigned dstr[NJD], xstr[NJX];
+  bool dln[NJD], xln[NJX];
+#pragma unroll
+  for (int j = 0; j < NJD; ++j) dln[j] = j * 256 + tid < DS;
+#pragma unroll
+  for (int j = 0; j < NJX; ++j) xln[j] = j * 256 + tid < XS;
+  const unsigned cbytes = (unsigned)(cstride * 4);
+  auto setup = [&](int tile) {
     const int tw_i = tile % a.ntw;
     int r = tile / a.ntw;
     const int th_i = r % a.nth;
     r /= a.nth;
-    const int t = r % a.T;
-    const int b = r / a.T;
-    const int tt = t + dt - (KT == 3 ? 1 : 0);
-    if (tt < 0 || tt >= a.T) continue;  // uniform: this time tap falls into the zero padding
+    const int t = t_lo + r % tv;
+    const int b = r / tv;
+    const int tt = t + dt - pt;
     const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
-
-    // ---- per-thread slots (2 each for dY and X planes)
-    int dofs[2], xofs[2];
-    unsigned dok = 0, dwr = 0, xok = 0, xwr = 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int p = j * 256 + tid;
-      dofs[j] = 0; xofs[j] = 0;
-      if (p < DS) {
-        dwr |= 1u << j;
-        const int hh = p / RS, ww = p - hh * RS;
-        const int gh = h0 + hh, gw = w0 + ww;
-        if (hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W) { dok |= 1u << j; dofs[j] = gh * a.W + gw; }
-      }
-      if (p < XS) {
-        xwr |= 1u << j;
-        const int hh = p / RS, ww = p - hh * RS;
-        const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-        if (hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) { xok |= 1u << j; xofs[j] = gh * a.W + gw; }
-      }
-    }
-
-    __syncthreads();  // previous tile's MFMA reads are done
     const float* dyb = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
     const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + tt) * HW;
-    const long cstride = (long)a.T * HW;
-#pragma unroll 4
-    for (int c = 0; c < 64; ++c) {
-      const bool ook = ob * 64 + c < a.Cout;
-      const bool cok = cb * 64 + c < a.Cin;
-      float sc = 1.f, sh = 0.f;
-      if (prologue && cok) { sc = a.in_scale[cb * 64 + c]; sh = a.in_shift[cb * 64 + c]; }
-      float dv[2], xv[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        dv[j] = (ook && ((dok >> j) & 1u)) ? dyb[c * cstride + dofs[j]] : 0.f;
-        xv[j] = (cok && ((xok >> j) & 1u)) ? xb[c * cstride + xofs[j]] : 0.f;
-      }
+    for (int j = 0; j < NJD; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
+      dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)a.zeros;
+      dstr[j] = ok ? cbytes : 0u;
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if ((dwr >> j) & 1u) dys[c * DS + j * 256 + tid] = dv[j];
-        if ((xwr >> j) & 1u) {
-          float val = xv[j];
-          if (prologue && cok && ((xok >> j) & 1u)) {
-            val = val * sc + sh;
-            if (a.in_lrelu) val = hpvg_lrelu(val);
-          }
-          xsm[c * XS + j * 256 + tid] = val;
-        }
+    for (int j = 0; j < NJX; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      const bool ok = hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)a.zeros;
+      xstr[j] = ok ? cbytes : 0u;
+    }
+  };
+  // stage the next channel row pair (channels are staged strictly in order 0,1,2,...): dY row c and X row c
+  float* dma_d = lds;   // LDS destinations of this wave for the channel being staged
+  float* dma_x = lds;
+  auto dma_begin = [&](float* buf) {
+    dma_d = buf + wave * 64;
+    dma_x = buf + 64 * DS + wave * 64;
+  };
+  auto dma_channel = [&](int c) {
+    if (c < no) {
+#pragma unroll
+      for (int j = 0; j < NJD; ++j) {
+        if (dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * 256), 4, 0, 0);
+        dptr[j] += dstr[j];
       }
     }
-    __syncthreads();
+    if (c < nc) {
+#pragma unroll
+      for (int j = 0; j < NJX; ++j) {
+        if (xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * 256), 4, 0, 0);
+        xptr[j] += xstr[j];
+      }
+    }
+    dma_d += DS;
+    dma_x += XS;
+  };
 
-    if (active) {
-      const float* dl = dys + (oblk * 32 + l31) * DS + half;
-      const float* xl = xsm + (cblk * 32 + l31) * XS + half;
-      for (int q0 = 0; q0 < a.QK; q0 += 2) {
-        const float av = dl[q0];
-        float bv[9];
-#pragma unroll
-        for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-          for (int dw = 0; dw < 3; ++dw) bv[dh * 3 + dw] = xl[q0 + dh * RS + dw];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
-      }
+  int tile = blockIdx.x;
+  __syncthreads();  // zero fill done
+  if (tile < ntiles) {
+    setup(tile);
+    dma_begin(lds);
+    for (int c = 0; c < 64; ++c) dma_channel(c);
+  }
+  __syncthreads();  // (waits for the DMA: pending LDS-DMA counts on vmcnt)
+
+  const int nsteps = a.QK >> 2;  // K-loop iterations (4 positions = 2 MFMA k-steps each)
+  int cur = 0;
+  for (; tile < ntiles; tile += a.S) {
+    const int next = tile + a.S;
+    const bool have_next = next < ntiles;
+    float* bufc = lds + cur * BUF;
+    int cnext = 64;                // next channel to stage (64 = nothing left)
+    if (have_next) {
+      setup(next);
+      dma_begin(lds + (cur ^ 1) * BUF);
+      cnext = 0;
     }
+    if (active) {
+      const float* dl = bufc + (oblk * 32 + l31) * DS + half;
+      const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + half;
+      // two register sets: the LDS reads of step st+1 are issued before the MFMAs of step st (1 wave per SIMD:
+      // nothing else hides the ds_read latency)
+      float pa0, pa1, pb0[9], pb1[9], qa0, qa1, qb0[9], qb1[9];
+#define WG_LOAD(A0, A1, B0, B1, ST)                                   \
+  {                                                                   \
+    const int q0_ = (ST) * 4;                                         \
+    A0 = dl[q0_];                                                     \
+    A1 = dl[q0_ + 2];                                                 \
+    _Pragma("unroll") for (int dh = 0; dh < 3; ++dh)                  \
+        _Pragma("unroll") for (int dw = 0; dw < 3; ++dw) {            \
+      B0[dh * 3 + dw] = xl[q0_ + dh * RS + dw];                       \
+      B1[dh * 3 + dw] = xl[q0_ + 2 + dh * RS + dw];                   \
+    }                                                                 \
+  }
+// 18 MFMAs with three channels of DMA staging slotted in between (rides in the matrix pipe's shadow)
+#define WG_MMA(A0, A1, B0, B1)                                                                                     \
+  {                                                                                                                \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0[k], acc[k], 0, 0, 0); \
+    if (cnext < 64) { dma_channel(cnext); ++cnext; }                                                               \
+    _Pragma("unroll") for (int k = 6; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0[k], acc[k], 0, 0, 0); \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[k], acc[k], 0, 0, 0); \
+    if (cnext < 64) { dma_channel(cnext); ++cnext; }                                                               \
+    _Pragma("unroll") for (int k = 3; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[k], acc[k], 0, 0, 0); \
+    if (cnext < 64) { dma_channel(cnext); ++cnext; }                                                               \
+  }
+      int st = 0;
+      if (st < nsteps) WG_LOAD(pa0, pa1, pb0, pb1, st);
+      for (; st + 1 < nsteps; st += 2) {
+        WG_LOAD(qa0, qa1, qb0, qb1, st + 1);
+        WG_MMA(pa0, pa1, pb0, pb1);
+        if (st + 2 < nsteps) WG_LOAD(pa0, pa1, pb0, pb1, st + 2);
+        WG_MMA(qa0, qa1, qb0, qb1);
+      }
+      if (st < nsteps) WG_MMA(pa0, pa1, pb0, pb1);
+#undef WG_LOAD
+#undef WG_MMA
+    }
+    while (cnext < 64) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
+    __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
+    cur ^= 1;
   }
 
   // ---- partial slab: part[s][dt][z][tap9][o64][c64]
@@ -219,15 +294,17 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
     for (int Th = 1; Th <= H; ++Th) {
       const int nth = hpvg_cdiv(H, Th);
       if (Th != hpvg_cdiv(H, nth)) continue;
-      const int QK = (Th * RS + 1) & ~1;
-      const int DS = (QK + 1) | 1;               // >= QK+1, odd
-      const int XS = ((Th + 2) * RS + 4) | 1;    // reads reach QK-1+1 + 2*RS+2 <= (Th+2)*RS + 3
+      const int QK = (Th * RS + 3) & ~3;                 // K positions, padded to the 4-position loop step
+      const int DS = (QK + 1) | 1;                       // dY row stride: >= QK, odd (bank spread)
+      int XS = QK + 2 * RS + 4;                          // X row: reads reach QK-1 + 2*RS + 2
+      if (XS < (Th + 2) * RS + 1) XS = (Th + 2) * RS + 1;
+      XS |= 1;
       if (DS > 512 || XS > 512) break;
-      const size_t lds = (size_t)64 * (DS + XS) * sizeof(float);
-      if (lds > 78 * 1024) break;
+      const size_t lds = (size_t)2 * 64 * (DS + XS) * sizeof(float);  // two tile buffers
+      if (lds > 156 * 1024) break;
       const long ntiles = (long)B * T * nth * ntw;
-      // useful fraction of the K loop and per-tile fixed cost (staging + two barriers)
-      const double work = (double)ntiles * (QK * 0.5 * 9.0 + 60.0);
+      // useful fraction of the K loop and per-tile fixed cost (barrier + pipeline segments)
+      const double work = (double)ntiles * (QK * 0.5 * 9.0 + 40.0);
       if (work < best_cost) {
         best_cost = work;
         best = WPlan{Th, Tw, RS, DS, XS, QK, nth, ntw, 0, nob, ncb, lds};
@@ -236,7 +313,7 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   }
   if (best.Th) {
     const long ntiles = (long)B * T * best.nth * best.ntw;
-    long cap = (2L * HPVG_NUM_CU) / ((long)KT * nob * ncb);
+    long cap = (long)HPVG_NUM_CU / ((long)KT * nob * ncb);  // one persistent workgroup per CU
     if (cap < 1) cap = 1;
     best.S = (int)(ntiles < cap ? ntiles : cap);
   }
@@ -249,7 +326,7 @@ extern "C" {
 
 size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
-  return (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+  return 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
 }
 
 // dw: natural layout [Cout][Cin][KT][3][3]; accumulate != 0 adds into dw instead of overwriting.
@@ -262,27 +339,45 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
-  const size_t need = (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+  const size_t need = 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
   if (ws_bytes < need) return HPVG_ERR_WORKSPACE;
   WgradArgs a;
-  a.dy = dy; a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.part = (float*)ws;
+  if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
+  a.dy = dy; a.x = x; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.zeros = (const float*)ws;                    // first 256 bytes of the workspace: zeros for padded positions
+  a.part = (float*)((char*)ws + 256);
+  if (hipMemsetAsync(ws, 0, 256, (hipStream_t)stream) != hipSuccess) return HPVG_ERR_LAUNCH;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
-  a.ntiles = B * T * p.nth * p.ntw; a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
+  a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr3 = false, attr1 = false;
   const dim3 grid(p.S, KT, p.nob * p.ncb);
-  if (KT == 3) {
-    if (!attr3) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); attr3 = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), p.lds, s, a);
-  } else {
-    if (!attr1) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); attr1 = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), p.lds, s, a);
+  const int njd = p.DS > 256 ? 2 : 1, njx = p.XS > 256 ? 2 : 1;
+#define HPVG_WG_LAUNCH(K, D, X)                                                                                        \
+  {                                                                                                                    \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<K, D, X>),                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
+        (void)hipGetLastError();                                                                                       \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_wgrad_kernel<K, D, X>), grid, dim3(256), p.lds, s, a);                                    \
   }
+  if (KT == 3) {
+    if (njd == 1 && njx == 1) HPVG_WG_LAUNCH(3, 1, 1)
+    else if (njd == 1) HPVG_WG_LAUNCH(3, 1, 2)
+    else HPVG_WG_LAUNCH(3, 2, 2)
+  } else {
+    if (njd == 1 && njx == 1) HPVG_WG_LAUNCH(1, 1, 1)
+    else if (njd == 1) HPVG_WG_LAUNCH(1, 1, 2)
+    else HPVG_WG_LAUNCH(1, 2, 2)
+  }
+#undef HPVG_WG_LAUNCH
   int st = hpvg_launch_status();
   if (st != HPVG_OK) return st;
   const long per_s = (long)KT * p.nob * p.ncb * 9 * 4096;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(hpvg_cdiv(per_s, 256)), dim3(256), 0, s, (const float*)ws, dw, p.S, KT,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(hpvg_cdiv(per_s, 256)), dim3(256), 0, s, (const float*)a.part, dw, p.S, KT,
                      p.nob, p.ncb, Cout, Cin, accumulate);
   return hpvg_launch_status();
 }
