@@ -23,8 +23,12 @@
 // (tap, m-tile); all workgroups read the same 442 KB so it stays L2 resident.
 // Accumulation is exact fp32 (v_mfma_f32_32x32x2_f32 == chain of fmaf).
 #include "hpvg_common.h"
+#include <stdlib.h>
 
 namespace {
+
+// source of zero padding for the LDS-DMA staging (out-of-image lanes read this word)
+__device__ const float g_zero_word[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 struct ConvFwdArgs {
   const float* x;
@@ -34,7 +38,7 @@ struct ConvFwdArgs {
   const float* in_shift;
   float* y;
   int B, Cin, Cout, T, H, W;
-  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, ntiles, mbtot, nj;
+  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, ntiles, mbtot, nj, S;
   int in_lrelu, out_lrelu;
 };
 
@@ -203,6 +207,188 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Pipelined variant (no fused producer on the input): one persistent workgroup per CU (1 wave per SIMD), two LDS
+// buffers.  While the MFMA loop of work item i = (tile, channel chunk) runs out of buffer i&1, item i+1 is staged
+// into the other buffer by LDS-DMA (global_load_lds_dword, no VGPR round trip), one input plane per tap slotted
+// between the MFMAs so that staging rides in the matrix pipe's shadow.  One barrier per item.
+template <int CC, int KT, int MB, int NB>
+__global__ __launch_bounds__(256, 1) void conv_mfma_pipe_kernel(const ConvFwdArgs a) {
+  constexpr int CP = CC / 2;
+  constexpr int TAPS = KT * 9;
+  constexpr int NPL = CC * KT;  // input planes per chunk
+  typedef typename AVecT<CP>::type AVec;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int mb0 = blockIdx.y * MB;
+  const long HW = (long)a.H * a.W;
+  const int RS = a.RS, PL = a.PL;
+  const int BUF = NPL * PL;
+  const int plload = (a.Th + 2) * RS;
+  const int pt = (KT == 3 ? 1 : 0);
+
+  // staging state of the tile being loaded
+  int goff[NJMAX];
+  bool gok[NJMAX], gln[NJMAX];
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) gln[j] = j < a.nj && j * 256 + tid < plload;
+  const float* sbase = a.x;  // x + b*Cin*T*HW of the staged tile
+  int st_t = 0;
+  auto setup = [&](int tile, int& b, int& t, int& h0, int& w0) {
+    const int tw_i = tile % a.ntw;
+    int r = tile / a.ntw;
+    const int th_i = r % a.nth;
+    r /= a.nth;
+    t = r % a.T;
+    b = r / a.T;
+    h0 = th_i * a.Th;
+    w0 = tw_i * a.Tw;
+#pragma unroll
+    for (int j = 0; j < NJMAX; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      gok[j] = gln[j] && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      goff[j] = gok[j] ? gh * a.W + gw : 0;
+    }
+    sbase = a.x + (long)b * a.Cin * a.T * HW;
+    st_t = t;
+  };
+  // stage input plane pl (= c*KT + dt) of channel chunk ch of the staged tile into buf
+  auto dma_plane = [&](int pl, int ch, float* buf) {
+    const int c = pl / KT, dt = pl - c * KT;
+    const int cg = ch * CC + c;
+    const int tt = st_t + dt - pt;
+    const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
+    const float* src = sbase + ((long)(valid ? cg : 0) * a.T + (valid ? tt : 0)) * HW;
+    float* dst = buf + pl * PL + wave * 64;
+#pragma unroll
+    for (int j = 0; j < NJMAX; ++j)
+      if (gln[j])
+        __builtin_amdgcn_global_load_lds((gptr_t)((valid && gok[j]) ? src + goff[j] : g_zero_word), (lptr_t)(dst + j * 256), 4, 0, 0);
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][i][e] = 0.f;
+
+  int tile = blockIdx.x;
+  if (tile >= a.ntiles) return;
+  int cb, ct, ch0, cw0;  // coordinates of the tile being computed (for its epilogue)
+  setup(tile, cb, ct, ch0, cw0);
+  for (int pl = 0; pl < NPL; ++pl) dma_plane(pl, 0, xs);
+  __syncthreads();
+
+  int cur = 0;
+  for (; tile < a.ntiles; tile += a.S) {
+    for (int ch = 0; ch < a.nchunk; ++ch) {
+      // ---- what to stage while computing (tile, ch)
+      const bool last_chunk = ch + 1 == a.nchunk;
+      int nch = ch + 1;
+      bool have_next = true;
+      int nb_, nt_, nh0_, nw0_;
+      if (last_chunk) {
+        nch = 0;
+        have_next = tile + a.S < a.ntiles;
+        if (have_next) setup(tile + a.S, nb_, nt_, nh0_, nw0_);
+      }
+      float* bufc = xs + cur * BUF;
+      float* bufn = xs + (cur ^ 1) * BUF;
+      int plnext = have_next ? 0 : NPL;
+
+      // ---- MFMA over (tap, channel pair) of the current chunk.  One wave per SIMD: nothing but this wave's own
+      // instruction order hides latency, so the B fragments of k-step s+1 are read from LDS before the MFMAs of
+      // k-step s (two register sets, static parity because CP is even) and the A fragments one tap ahead.
+      const float* xl = bufc + half * KT * PL + l31 + wave * 32;
+      const AVec* wpt = reinterpret_cast<const AVec*>(a.wp) + ((long)(ch * TAPS) * a.mbtot + mb0) * 64 + lane;
+      AVec av[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) av[m] = wpt[m * 64];
+      float bv[2][NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) bv[0][i] = xl[i * 128];
+#pragma unroll 1
+      for (int dt = 0; dt < KT; ++dt) {
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            wpt += (long)a.mbtot * 64;
+            AVec an[MB];
+            const float* xt = xl + dt * PL + dh * RS + dw;
+            // first k-step of the NEXT tap (past the chunk's last tap this is a harmless in-buffer read)
+            const float* xn = (dw < 2) ? xt + 1 : (dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1) * PL);
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) {
+              const float* nx = (cp + 1 < CP) ? xt + (2 * (cp + 1) * KT) * PL : xn;
+#pragma unroll
+              for (int i = 0; i < NB; ++i) bv[(cp + 1) & 1][i] = nx[i * 128];
+              __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this k-step's MFMAs
+#pragma unroll
+              for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                  acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[cp & 1][i], acc[m][i], 0, 0, 0);
+              if (cp == 0) {
+                // next tap's A fragments and one plane of DMA staging, issued right AFTER this tap's first MFMA
+                // group: with LDS-DMA in flight hipcc waits vmcnt(0) (not a counted wait) at the first use of an
+                // ordinary load, so every VMEM op must be >= ~3/4 tap old when the next tap starts
+#pragma unroll
+                for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
+                if (plnext < NPL) { dma_plane(plnext, nch, bufn); ++plnext; }
+              }
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) av[m] = an[m];
+          }
+        }
+      }
+      while (plnext < NPL) { dma_plane(plnext, nch, bufn); ++plnext; }
+
+      if (last_chunk) {
+        // ---- epilogue of the finished tile: bias, optional LeakyReLU, masked store; then reset the accumulators
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int blk = wave + 4 * i;
+          const int q = blk * 32 + l31;
+          const int hh = q / RS, ww = q - hh * RS;
+          const int gh = ch0 + hh, gw = cw0 + ww;
+          const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
+          const long sp = (long)ct * HW + (long)gh * a.W + gw;
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+              if (ok && co < a.Cout) {
+                float val = acc[m][i][e];
+                if (a.bias) val += a.bias[co];
+                if (a.out_lrelu) val = hpvg_lrelu(val);
+                a.y[((long)cb * a.Cout + co) * a.T * HW + sp] = val;
+              }
+              acc[m][i][e] = 0.f;
+            }
+          }
+        }
+        cb = nb_; ct = nt_; ch0 = nh0_; cw0 = nw0_;
+      }
+      __syncthreads();  // staged buffer complete (the barrier's fence waits for pending LDS-DMA); current one free
+      cur ^= 1;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // weight pack: natural [Cout][Cin][taps] -> MFMA A-fragment order
 //   wp[chunk][tap][mblock][lane][cp] = Wsrc[o = mblock*32 + (lane&31)][c = chunk*CC + 2cp + (lane>>5)][tap]
@@ -237,11 +423,12 @@ inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
 
 struct Plan {
   int Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, nj;
-  size_t lds;
+  size_t lds;      // bytes of ONE tile buffer (the pipelined kernel uses two)
+  bool pipelined;
 };
 
 // Tile planner: minimise (waves of workgroups over the chip) x (per-workgroup MFMA rounds).
-Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
   const int CC = conv_cc(Cin);
   const int mbtot = hpvg_cdiv(Cout, 32);
   Plan best{};
@@ -265,17 +452,27 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT) {
         const int need = 128 * NB + 2 * RS + 2;
         if (PL < need) PL = need;
         const size_t lds = (size_t)CC * KT * PL * sizeof(float);
-        if (lds > 160 * 1024) continue;
-        const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+        if (lds > (pipelined ? 78 : 160) * 1024) continue;
+        const int per_cu = pipelined ? 1 : (lds <= 80 * 1024 ? 2 : 1);
         const long nwg = (long)B * T * nth * ntw * gridy;
         const long slots = (long)HPVG_NUM_CU * per_cu;
-        const double waves = nwg <= slots ? 1.0 : (double)nwg / (double)slots;
-        // per-WG time ~ MFMA rounds (scaled by m-tiles) + fixed staging/sync overhead
-        const double per = (double)NB * MB + 0.6 + 0.002 * (Th + 2) * RS;
-        const double cost = waves * per + 5e-4 * (double)nwg;  // tie-break: fewer, fuller workgroups
+        double cost;
+        if (pipelined) {
+          // persistent workgroups walk ceil(ntiles/S) tiles each; staging is hidden behind the MFMA loop
+          long S = slots / gridy;
+          if (S < 1) S = 1;
+          const long ntl = nwg / gridy;
+          const double rounds = (double)((ntl + S - 1) / S);
+          cost = rounds * ((double)NB * MB + 0.15) + 5e-4 * (double)nwg;
+        } else {
+          const double waves = nwg <= slots ? 1.0 : (double)nwg / (double)slots;
+          // per-WG time ~ MFMA rounds (scaled by m-tiles) + fixed staging/sync overhead
+          const double per = (double)NB * MB + 0.6 + 0.002 * (Th + 2) * RS;
+          cost = waves * per + 5e-4 * (double)nwg;  // tie-break: fewer, fuller workgroups
+        }
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
-          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds};
+          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds, pipelined};
         }
       }
     }
@@ -285,7 +482,18 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT) {
 
 template <int CC, int KT, int MB, int NB>
 int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
-  static bool attr_set = false;
+  static bool attr_set = false, attr_set2 = false;
+  if (p.pipelined) {
+    auto kern = conv_mfma_pipe_kernel<CC, KT, MB, NB>;
+    if (!attr_set2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess)
+        (void)hipGetLastError();
+      attr_set2 = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.S, p.gridy), dim3(256), 2 * p.lds, s, a);
+    return hpvg_launch_status();
+  }
   auto kern = conv_mfma_kernel<CC, KT, MB, NB>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -353,7 +561,19 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
-  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT);
+  // development knob: HPVG_CONV_PIPE=0/1 forces the kernel variant (default: auto)
+  static const int force = [] { const char* e = getenv("HPVG_CONV_PIPE"); return e ? atoi(e) : -1; }();
+  // Variant choice (measured, tools/perf_conv.py): when the classic grid fits on the chip in one wave of workgroups
+  // (<= 512) the launch is latency bound and the software-pipelined persistent kernel wins (stage 0: 135 -> 92 us);
+  // for larger grids two co-resident workgroups per CU hide each other's staging better than one wave per SIMD can.
+  bool pipelined = false;
+  if (in_scale == nullptr) {
+    const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
+    pipelined = (long)B * T * pc.nth * pc.ntw * pc.gridy <= 2L * HPVG_NUM_CU;
+  }
+  if (force == 0) pipelined = false;
+  if (force == 1 && in_scale == nullptr) pipelined = true;
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, pipelined);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
   ConvFwdArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y;
@@ -364,6 +584,11 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   a.ntiles = B * T * p.nth * p.ntw;
   a.mbtot = hpvg_cdiv(Cout, 32);
   a.nj = p.nj;
+  {
+    long S = HPVG_NUM_CU / p.gridy;
+    if (S < 1) S = 1;
+    a.S = (int)(a.ntiles < S ? a.ntiles : S);
+  }
   a.in_lrelu = in_lrelu; a.out_lrelu = out_lrelu;
   hipStream_t s = (hipStream_t)stream;
   if (CC == 8) return KT == 3 ? dispatch_conv<8, 3>(a, p, s) : dispatch_conv<8, 1>(a, p, s);
@@ -374,7 +599,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
 // out[0..9] = Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds_bytes, ntiles
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
   if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
-  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT);
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
   out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
   out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
   return HPVG_OK;
