@@ -220,6 +220,211 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Narrow backward-weight: one side of the layer has <= 4 channels (heads 3->64, tails 64->3 / 64->1).
+//   R[cw][cn][tap] = sum_pos wide[cw][pos] * narrow[cn][pos + off(tap)]          (all KT*9 taps at once)
+// head (Cin <= 4):  wide = dY (Cout ch), narrow = X          ->  dW[o=cw][c=cn][tap]        = R
+// tail (Cout <= 4): wide = X (Cin ch),  narrow = dY (halo'd) ->  dW[o=cn][c=cw][ntaps-1-tap] = R
+// GEMM: M = wide channels (2 tiles of 32 per 64-block), N = (cn, tap) pairs (<= 108 -> up to 4 tiles of 32, read
+// from the halo'd narrow tile through a per-lane offset), K = positions of the tile, split over the 4 waves.
+// The wide operand is streamed exactly once (HBM bound); staging is LDS-DMA, double buffered, like conv_wgrad_kernel.
+struct NarrowArgs {
+  const float* wide;
+  const float* narrow;
+  const float* zeros;
+  float* part;
+  int B, CW, CN, T, H, W;
+  int Th, Tw, RS, DS, XPL, QK, nth, ntw, S, ntiles;
+};
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_narrow_kernel(const NarrowArgs a) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int TAPS = KT * 9;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wb = blockIdx.y;  // 64-channel block of the wide operand
+  const int RS = a.RS, DS = a.DS, XPL = a.XPL;
+  const int NROW = a.CN * KT;           // narrow planes
+  const int BUF = 64 * DS + NROW * XPL;
+  const long HW = (long)a.H * a.W;
+  const long cstride = (long)a.T * HW;
+  const unsigned cbytes = (unsigned)(cstride * 4);
+  const int pt = (KT == 3 ? 1 : 0);
+  int nw = a.CW - wb * 64; if (nw > 64) nw = 64;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
+
+  // per-lane offset of column j = n*32 + (lane&31) -> (cn, tap) inside the halo'd narrow tile
+  int loff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int j = n * 32 + l31;
+    int o = 0;
+    if (j < a.CN * TAPS) {
+      const int cn = j / TAPS, tap = j - cn * TAPS;
+      const int dt = tap / 9, r = tap - dt * 9, dh = r / 3, dw = r - dh * 3;
+      o = (cn * KT + dt) * XPL + dh * RS + dw;
+    }
+    loff[n] = o;
+  }
+
+  // staging state (2 slots of 256 positions for the wide rows, 2 for the narrow planes)
+  const char* wptr[2];
+  unsigned wstr[2];
+  int noff[2];
+  bool nok[2];
+  const bool wln[2] = {tid < DS, 256 + tid < DS};
+  const bool nln[2] = {tid < XPL, 256 + tid < XPL};
+  const float* nbase = a.narrow;
+  int st_t = 0;
+  auto setup = [&](int tile) {
+    const int tw_i = tile % a.ntw;
+    int r = tile / a.ntw;
+    const int th_i = r % a.nth;
+    r /= a.nth;
+    const int t = r % a.T;
+    const int b = r / a.T;
+    const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
+    const float* wbp = a.wide + (((long)b * a.CW + wb * 64) * a.T + t) * HW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
+      wptr[j] = ok ? (const char*)(wbp + gh * a.W + gw) : (const char*)a.zeros;
+      wstr[j] = ok ? cbytes : 0u;
+      const int gh2 = h0 + hh - 1, gw2 = w0 + ww - 1;
+      nok[j] = hh < a.Th + 2 && gh2 >= 0 && gh2 < a.H && gw2 >= 0 && gw2 < a.W;
+      noff[j] = nok[j] ? gh2 * a.W + gw2 : 0;
+    }
+    nbase = a.narrow + (long)b * a.CN * a.T * HW;
+    st_t = t;
+  };
+  float* dma_w = lds;
+  auto dma_begin = [&](float* buf) { dma_w = buf + wave * 64; };
+  auto dma_wide = [&](int c) {  // rows strictly in order c = 0, 1, 2, ...
+    if (c < nw) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (wln[j]) __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(dma_w + j * 256), 4, 0, 0);
+        wptr[j] += wstr[j];
+      }
+    }
+    dma_w += DS;
+  };
+  auto dma_narrow = [&](int row, float* buf) {  // row = cn*KT + dt
+    const int cn = row / KT, dt = row - cn * KT;
+    const int tt = st_t + dt - pt;
+    const bool valid = tt >= 0 && tt < a.T;
+    const float* src = nbase + ((long)cn * a.T + (valid ? tt : 0)) * HW;
+    float* dst = buf + 64 * DS + row * XPL + wave * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (nln[j]) __builtin_amdgcn_global_load_lds((gptr_t)((valid && nok[j]) ? src + noff[j] : a.zeros), (lptr_t)(dst + j * 256), 4, 0, 0);
+  };
+
+  int tile = blockIdx.x;
+  __syncthreads();
+  if (tile < a.ntiles) {
+    setup(tile);
+    dma_begin(lds);
+    for (int c = 0; c < 64; ++c) dma_wide(c);
+    for (int r = 0; r < NROW; ++r) dma_narrow(r, lds);
+  }
+  __syncthreads();
+
+  // this wave's share of the K positions: [k_lo, k_hi) in steps of 2
+  const int nk = a.QK >> 1;
+  const int k_lo = (wave * nk) / 4, k_hi = ((wave + 1) * nk) / 4;
+  int cur = 0;
+  for (; tile < a.ntiles; tile += a.S) {
+    const int next = tile + a.S;
+    const bool have_next = next < a.ntiles;
+    float* bufc = lds + cur * BUF;
+    float* bufn = lds + (cur ^ 1) * BUF;
+    int cnext = 64, rnext = NROW;
+    if (have_next) {
+      setup(next);
+      dma_begin(bufn);
+      cnext = 0;
+      rnext = 0;
+    }
+    const float* al = bufc + l31 * DS + half;
+    const float* bl = bufc + 64 * DS + half;
+    for (int ks = k_lo; ks < k_hi; ++ks) {
+      const int q0 = ks * 2;
+      const float a0 = al[q0], a1 = al[32 * DS + q0];
+      float bv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bv[n] = bl[loff[n] + q0];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[n], acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[n], acc[1][n], 0, 0, 0);
+      }
+      // staging of the next tile, a few rows per k-step
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        if (cnext < 64) { dma_wide(cnext); ++cnext; }
+      if (rnext < NROW) { dma_narrow(rnext, bufn); ++rnext; }
+    }
+    while (cnext < 64) { dma_wide(cnext); ++cnext; }
+    while (rnext < NROW) { dma_narrow(rnext, bufn); ++rnext; }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // partial fragments: part[(wg*4 + wave)][wb][m][n][e][lane]
+  float* pp = a.part + ((((long)blockIdx.x * 4 + wave) * gridDim.y + wb) * 2 * NT) * 1024;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pp[((m * NT + n) * 16 + e) * 64 + lane] = acc[m][n][e];
+}
+
+// dW from the narrow kernel's fragments; mode 0: dW[o=cw][c=cn][tap]; mode 1: dW[o=cn][c=cw][ntaps-1-tap]
+__global__ void conv_wgrad_narrow_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts, int nwb,
+                                                int NT, int CW, int CN, int taps, int mode, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = CW * CN * taps;
+  if (idx >= total) return;
+  const int tap = idx % taps;
+  const int cn = (idx / taps) % CN;
+  const int cw = idx / (taps * CN);
+  const int wb = cw / 64, c64 = cw % 64;
+  const int m = c64 / 32, row = c64 % 32;
+  const int hf = (row >> 2) & 1, e = (row & 3) + 4 * (row >> 3);
+  const int j = cn * taps + tap;
+  const int n = j / 32, col = j % 32;
+  const long off = ((long)(wb * 2 * NT) + (m * NT + n)) * 1024 + e * 64 + hf * 32 + col;
+  const long pstride = (long)nwb * 2 * NT * 1024;
+  float s0 = 0.f, s1 = 0.f;
+  int p = 0;
+  for (; p + 2 <= nparts; p += 2) {
+    s0 += part[(long)p * pstride + off];
+    s1 += part[(long)(p + 1) * pstride + off];
+  }
+  if (p < nparts) s0 += part[(long)p * pstride + off];
+  const float tot = s0 + s1;
+  float* dst = mode == 0 ? dw + ((long)cw * CN + cn) * taps + tap : dw + ((long)cn * CW + cw) * taps + (taps - 1 - tap);
+  *dst = accumulate ? *dst + tot : tot;
+}
+
 // dW[o][c][dt][tap9] = sum_s part[s][dt][z][tap9][o%64][c%64]; one thread per slab element, fixed order.
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int KT, int nob,
                                          int ncb, int Cout, int Cin, int accumulate) {
@@ -320,12 +525,29 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   return best;
 }
 
+// narrow path selection: 0 = head (Cin <= 4), 1 = tail (Cout <= 4), -1 = full kernel
+inline int narrow_mode(int Cin, int Cout) {
+  if (Cin <= 4 && Cout > 4) return 0;
+  if (Cout <= 4 && Cin > 4) return 1;
+  return -1;
+}
+inline size_t narrow_ws_bytes(const WPlan& p, int CW, int CN, int KT, long ntiles) {
+  const int nwb = hpvg_cdiv(CW, 64);
+  const int NT = hpvg_cdiv(CN * KT * 9, 32);
+  long S = HPVG_NUM_CU / nwb;
+  if (S < 1) S = 1;
+  if (ntiles < S) S = ntiles;
+  return 256 + (size_t)S * 4 * nwb * 2 * NT * 1024 * sizeof(float);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
+  const int nm = narrow_mode(Cin, Cout);
+  if (nm >= 0) return narrow_ws_bytes(p, nm == 0 ? Cout : Cin, nm == 0 ? Cin : Cout, KT, (long)B * T * p.nth * p.ntw);
   return 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
 }
 
@@ -339,6 +561,51 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  const int nm = narrow_mode(Cin, Cout);
+  if (nm >= 0) {
+    // ---- narrow layer (head / tail): dedicated kernel, the wide operand is streamed once
+    if (in_scale) return HPVG_ERR_UNSUPPORTED;
+    const int CW = nm == 0 ? Cout : Cin, CN = nm == 0 ? Cin : Cout;
+    const long ntiles = (long)B * T * p.nth * p.ntw;
+    if (ws_bytes < narrow_ws_bytes(p, CW, CN, KT, ntiles)) return HPVG_ERR_WORKSPACE;
+    const int nwb = hpvg_cdiv(CW, 64);
+    const int NT = hpvg_cdiv(CN * KT * 9, 32);
+    long S = HPVG_NUM_CU / nwb;
+    if (S < 1) S = 1;
+    if (ntiles < S) S = ntiles;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) return HPVG_ERR_LAUNCH;
+    NarrowArgs na;
+    na.wide = nm == 0 ? dy : x; na.narrow = nm == 0 ? x : dy; na.zeros = (const float*)ws; na.part = (float*)((char*)ws + 256);
+    na.B = B; na.CW = CW; na.CN = CN; na.T = T; na.H = H; na.W = W;
+    na.Th = p.Th; na.Tw = p.Tw; na.RS = p.RS; na.DS = p.DS; na.XPL = p.XS; na.QK = p.QK; na.nth = p.nth; na.ntw = p.ntw;
+    na.S = (int)S; na.ntiles = (int)ntiles;
+    const size_t lds = (size_t)2 * (64 * p.DS + CN * KT * p.XS) * sizeof(float);
+    const dim3 grid((unsigned)S, nwb);
+#define HPVG_NW_LAUNCH(K, N)                                                                                          \
+  {                                                                                                                   \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_narrow_kernel<K, N>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                  \
+        (void)hipGetLastError();                                                                                      \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((conv_wgrad_narrow_kernel<K, N>), grid, dim3(256), lds, s, na);                                \
+  }
+    if (KT == 3) {
+      if (NT == 1) HPVG_NW_LAUNCH(3, 1) else if (NT == 2) HPVG_NW_LAUNCH(3, 2) else if (NT == 3) HPVG_NW_LAUNCH(3, 3) else HPVG_NW_LAUNCH(3, 4)
+    } else {
+      if (NT == 1) HPVG_NW_LAUNCH(1, 1) else HPVG_NW_LAUNCH(1, 2)
+    }
+#undef HPVG_NW_LAUNCH
+    int st = hpvg_launch_status();
+    if (st != HPVG_OK) return st;
+    const int total = CW * CN * KT * 9;
+    hipLaunchKernelGGL(conv_wgrad_narrow_reduce_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, s, (const float*)na.part, dw,
+                       (int)S * 4, nwb, NT, CW, CN, KT * 9, nm, accumulate);
+    return hpvg_launch_status();
+  }
   const size_t need = 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
   if (ws_bytes < need) return HPVG_ERR_WORKSPACE;
   WgradArgs a;
