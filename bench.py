@@ -183,8 +183,8 @@ def main():
     from hp_vae_gan_amd import ops
 
     if world > 1:
-        from hp_vae_gan_amd import pipeline
-        runner = pipeline.build_bench_runner(video_opt, stages, device, rank, world)
+        from hp_vae_gan_amd import multigpu
+        runner = multigpu.build_bench_runner(video_opt, stages, device, rank, world)
     else:
         built, shapes = build_gpu_stages(device, stages)
 
@@ -266,7 +266,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2]); "
                                    "step = 1 train iteration at each pyramid stage %s" % args.stages,
-                       "stages": stages, "parallelism": "single GPU" if world == 1 else "level pipeline x%d" % world},
+                       "stages": stages, "parallelism": "single GPU" if world == 1 else "rec/rand generator passes on ranks 0/1 + discriminator work split over the batch (2 working ranks of %d)" % world},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
             "roofline": roof, "cpu_baseline": cpu,
         }

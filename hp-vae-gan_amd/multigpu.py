@@ -1,0 +1,271 @@
+"""Multi-GPU execution of one train iteration: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU node, "gloo" in the CPU tests).
+
+What shards.  Stages are strictly sequential and, inside an iteration, pyramid levels form a chain, so
+the path does not split into independent units.  What does split in a GAN stage:
+
+  * the two generator passes of an iteration are independent: rank 0 runs the reconstruction pass (mode="rec") and its
+    backward, rank 1 the random pass (mode="rand") and its backward;
+  * the discriminator has no BatchNorm (spectral norm only), so every D evaluation is separable over the batch
+    dimension (batch_size 2): rank b evaluates D(real[b]), D(fake[b]), the gradient penalty of sample b and, in the G
+    step, D(fake[b]).  The WGAN means are over (batch, voxels), i.e. 0.5 * (per-sample mean) each.
+
+Exchange steps (point-to-point over one xGMI link, latency bound, <= 3.9 MB): fake[0] rank 1 -> rank 0, and its
+gradient dfake[0] rank 0 -> rank 1 (this is the level output that BASELINE.json's north_star ships between GPUs).
+Collectives: one all-reduce of the flat D gradient arena (2.2 MB) and one of the flat G gradient arena per
+iteration, a 1-float broadcast of the GP alpha and of the calibrated noise amplitude.  Both ranks then apply the
+identical Adam update, so the replicas stay bit-identical.  With both ranks busy the step costs
+max(rec pass, rand pass) + half the D work: <= 2x over one GPU.  More than two ranks add nothing here (batch is 2,
+the last level holds ~81 % of the work): ranks >= 2 idle, and bench.py reports that honestly.
+
+VAE stages (scale_idx < vae_levels) have a single generator pass with BatchNorm over the batch: every rank runs the
+identical step (noise broadcast from rank 0), which keeps the replicas in sync at no extra speed.
+
+BatchNorm running statistics / SN u,v of the generator are advanced only by the pass a rank executes (they never
+influence training: the reference keeps netG in train mode for every forward); `sync_buffers()` averages them at the
+end of a stage.
+
+The arithmetic is delegated to a `backend` (HipBackend below: the gfx950 kernels; the gloo tests plug in a torch-CPU
+backend built on the oracle) so that the distributed logic is testable without a GPU."""
+import torch
+import torch.distributed as dist
+
+
+class HipBackend:
+    """Losses / optimisers of the product path (gfx950 kernels)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+
+    def mse(self, a, b):
+        from .modules.losses import mse_loss
+        return mse_loss(a, b)
+
+    def kl(self, mu, logvar):
+        from .modules.losses import kl_criterion
+        return kl_criterion(mu, logvar)
+
+    def wgan_mean(self, x, sign):
+        from .modules.losses import wgan_mean
+        return wgan_mean(x, sign)
+
+    def grad_penalty(self, netD, real, fake, lam, alpha):
+        from .modules.utils import calc_gradient_penalty
+        return calc_gradient_penalty(netD, real, fake, lam, real.device, alpha=alpha)
+
+    def optimizers(self, netG, netD, g_groups, lr_d, beta1):
+        from . import optim as hp_optim
+
+        class _Opt:
+            pass
+
+        o = _Opt()
+        o.arenaG = hp_optim.ParamArena(netG)
+        o.optG = hp_optim.FlatAdam(o.arenaG, g_groups, betas=(beta1, 0.999))
+        o.allreduce_G = lambda group=None: dist.all_reduce(o.arenaG.grad, group=group)  # ONE collective for all of G
+        o.zero_G = o.arenaG.zero_grad
+        o.clip_step_G = lambda max_norm: (o.arenaG.clip_grad_norm_(max_norm), o.optG.step())
+        if netD is not None:
+            o.arenaD = hp_optim.ParamArena(netD)
+            o.optD = hp_optim.FlatAdam(o.arenaD, [(netD.parameters(), lr_d)], betas=(beta1, 0.999))
+            o.allreduce_D = lambda group=None: dist.all_reduce(o.arenaD.grad, group=group)
+            o.zero_D = o.arenaD.zero_grad
+            o.step_D = o.optD.step
+        return o
+
+    def noise(self, ref):
+        from . import utils
+        return utils.generate_noise(ref=ref)
+
+
+class DistStageTrainer:
+    """One pyramid stage on `world` ranks (see module docstring).  Mirrors train.StageTrainer.step()."""
+
+    def __init__(self, opt, netG, netD, backend, g_groups, group=None):
+        self.opt, self.netG, self.netD, self.be = opt, netG, netD, backend
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.is_gan = opt.vae_levels < opt.scale_idx + 1
+        if self.is_gan and opt.batch_size != 2:
+            raise NotImplementedError("the batch split of the discriminator work assumes batch_size == 2 (reference default)")
+        self.active = self.rank < 2 or not self.is_gan     # GAN stages: two working ranks
+        # collectives of a GAN stage run over the two working ranks only
+        self.pair = dist.new_group(ranks=[0, 1]) if self.world > 2 else None
+        self.o = backend.optimizers(netG, netD if self.is_gan else None, g_groups, opt.lr_d, opt.beta1)
+        self.iteration = 0
+        self.dev = next(netG.parameters()).device
+
+    # ---- tiny helpers
+    def _bcast_float(self, value, src=0, group=None):
+        t = torch.tensor([float(value) if value is not None else 0.0], dtype=torch.float64, device=self.dev)
+        dist.broadcast(t, src=src, group=group)
+        return float(t.item())
+
+    def _bcast_noise(self, ref):
+        n = self.be.noise(ref) if self.rank == 0 else torch.empty_like(ref)
+        dist.broadcast(n, src=0)
+        return n
+
+    def calibrate_noise_amp(self, real, real_zero):
+        opt = self.opt
+        if opt.const_amp:
+            opt.Noise_Amps.append(1)
+            return
+        if opt.scale_idx == 0:
+            opt.noise_amp = 1
+            opt.Noise_Amps.append(1)
+            return
+        opt.Noise_Amps.append(0)
+        amp = 0.0
+        if self.rank == 0 or not self.is_gan:
+            with torch.no_grad():
+                rec, _, _ = self.netG(real_zero, opt.Noise_Amps, mode="rec")
+                amp = opt.noise_amp_init * float(torch.sqrt(self.be.mse(real, rec)).item()) / opt.batch_size
+        if self.is_gan:
+            amp = self._bcast_float(amp, 0)
+        opt.noise_amp = amp
+        opt.Noise_Amps[-1] = amp
+
+    # ---- one iteration
+    def step(self, real, real_zero, noise_init=None, alpha=None):
+        opt = self.opt
+        if not self.is_gan:
+            return self._vae_step(real, real_zero)
+        if self.iteration == 0:
+            self.calibrate_noise_amp(real, real_zero)
+        self.iteration += 1
+        if not self.active:
+            return {}
+        r, g = self.rank, self.pair
+        netG, netD, be, o = self.netG, self.netD, self.be, self.o
+        out = {}
+        # -- generator passes: rec on rank 0, rand on rank 1
+        if r == 0:
+            generated, _, _ = netG(real_zero, opt.Noise_Amps, mode="rec")
+            fake_b = torch.empty_like(real[0:1])
+            dist.recv(fake_b, src=1)
+        else:
+            if noise_init is None:
+                noise_init = be.noise(torch.empty(opt.Z_init_size, device=self.dev))
+            fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
+            dist.send(fake[0:1].detach().contiguous(), dst=0)
+            fake_b = fake[1:2].detach().contiguous()
+        real_b = real[r:r + 1].contiguous()
+        # -- D step on this rank's batch sample (same alpha on both ranks, drawn on rank 0's CPU generator)
+        if alpha is None:
+            alpha = torch.rand(1, 1) if r == 0 else torch.zeros(1, 1)
+        a = alpha.reshape(1).to(self.dev, torch.float32).clone()
+        dist.broadcast(a, src=0, group=g)
+        o.zero_D()
+        errD_real = be.wgan_mean(netD(real_b), -1.0) * 0.5
+        errD_fake = be.wgan_mean(netD(fake_b), 1.0) * 0.5
+        gp = be.grad_penalty(netD, real_b, fake_b, opt.lambda_grad, a) * 0.5
+        (errD_real + errD_fake + gp).backward()
+        o.allreduce_D(g)
+        o.step_D()
+        # -- G step: critic term of this rank's sample, gradient w.r.t. the sample goes back to the rand pass owner
+        leaf = fake_b.detach().requires_grad_(True)
+        for p in netD.parameters():
+            p.requires_grad_(False)
+        errG_b = be.wgan_mean(netD(leaf), -1.0) * (0.5 * opt.disc_loss_weight)
+        (dfake_b,) = torch.autograd.grad(errG_b, leaf)
+        for p in netD.parameters():
+            p.requires_grad_(True)
+        o.zero_G()
+        if r == 0:
+            dist.send(dfake_b.contiguous(), dst=1)
+            rec_loss = be.mse(generated, real)
+            (opt.rec_weight * rec_loss).backward()
+            out["rec_loss"] = rec_loss.detach()
+        else:
+            dfake0 = torch.empty_like(dfake_b)
+            dist.recv(dfake0, src=0)
+            fake.backward(torch.cat([dfake0, dfake_b], dim=0))
+        o.allreduce_G(g)
+        o.clip_step_G(opt.grad_clip)
+        stats = torch.stack([errD_real.detach(), errD_fake.detach(), gp.detach(), errG_b.detach()]).reshape(4).clone()
+        dist.all_reduce(stats, group=g)
+        out.update(errD_real=stats[0], errD_fake=stats[1], gradient_penalty=stats[2], errG=stats[3])
+        return out
+
+    def _vae_step(self, real, real_zero):
+        """Single generator pass with BatchNorm over the batch: every rank runs the identical step."""
+        opt, netG, be, o = self.opt, self.netG, self.be, self.o
+        prev = netG.noise_source
+        netG.noise_source = self._bcast_noise
+        try:
+            if self.iteration == 0:
+                self.calibrate_noise_amp(real, real_zero)
+            self.iteration += 1
+            generated, generated_vae, (mu, logvar) = netG(real_zero, opt.Noise_Amps, mode="rec")
+            rec_vae_loss = be.mse(generated, real) + be.mse(generated_vae, real_zero)
+            kl_loss = be.kl(mu, logvar)
+            total = opt.rec_weight * rec_vae_loss + opt.kl_weight * kl_loss
+            o.zero_G()
+            total.backward()
+            o.clip_step_G(opt.grad_clip)
+        finally:
+            netG.noise_source = prev
+        return {"rec_vae_loss": rec_vae_loss.detach(), "kl_loss": kl_loss.detach(), "total_loss": total.detach()}
+
+    def sync_buffers(self):
+        """Average the generator's buffers (BN running stats, SN u/v) over the working ranks at the end of a stage."""
+        n = 2 if (self.is_gan and self.world >= 2) else 1
+        if n == 1 or not self.active:
+            return
+        for b in self.netG.buffers():
+            if b.dtype.is_floating_point:
+                dist.all_reduce(b, group=self.pair)
+                b.div_(n)
+
+
+def build_bench_runner(make_opt, stages, device, rank, world):
+    """bench.py's N>1 path: one DistStageTrainer per pyramid stage with synthetic resident inputs."""
+    import copy
+    from . import train as hp_train
+    from . import utils as hu
+    from .modules import networks_3d
+    torch.manual_seed(0)  # identical replicas on every rank
+    base = make_opt(device)
+    hu.adjust_scales2image(base.img_size, base)
+    base.stop_scale_time = base.stop_scale
+    proto = networks_3d.GeneratorHPVAEGAN(base)
+    built = []
+    for s in range(base.stop_scale + 1):
+        if s > 0:
+            proto.init_next_stage()
+        if s not in stages:
+            continue
+        opt = make_opt(device)
+        hu.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+        opt.scale_idx = s
+        opt.Noise_Amps = [1] + [0.05] * max(0, s - 1)
+        netG = copy.deepcopy(proto)
+        netG.opt = opt
+        netG.to(device)
+        netD = None
+        if opt.vae_levels < s + 1:
+            torch.manual_seed(1000 + s)
+            netD = networks_3d.WDiscriminator3D(opt).to(device)
+        shapes = [hu.images.level_shape_3d(i, opt) for i in range(s + 1)]
+        g = torch.Generator().manual_seed(100 + s)
+        real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
+        real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
+        opt.Z_init_size = [opt.batch_size, opt.latent_dim, *shapes[0]]
+        trainer = DistStageTrainer(opt, netG, netD, HipBackend(opt), hp_train.generator_param_groups(opt, netG))
+        built.append((s, trainer, real, real_zero))
+
+    class Runner:
+        n = len(built)
+
+        def step(self):
+            for s, trainer, real, real_zero in built:
+                trainer.step(real, real_zero)
+
+        def timed_stage(self, idx):
+            s, trainer, real, real_zero = built[idx]
+            trainer.step(real, real_zero)
+            return s
+
+    return Runner()

@@ -203,10 +203,13 @@ def num_body(P):
 
 def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True):
     """GeneratorHPVAEGAN.forward.  `noises` is an iterator yielding the N(0,1) draws in reference order
-    (reparameterisation eps first, then one tensor per noisy level)."""
+    (reparameterisation eps first, then one tensor per noisy level), or a callable(shape) -> tensor."""
+    def draw(shape):
+        return noises(tuple(shape)) if callable(noises) else next(noises)
+
     if noise_init is None:
         mu, logvar = encoder_forward(video, P, opt, training)
-        eps = next(noises)
+        eps = draw(mu.shape)
         z = eps * torch.exp(0.5 * logvar) + mu if training else eps
     else:
         z = noise_init
@@ -219,7 +222,7 @@ def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='ran
                 vae_out = x  # reference detaches IN PLACE (networks_3d.py:392): the returned vae_out is cut too
         up = resize_linear_ac(x, level_shape(idx + 1, opt, dims))
         inject = mode == 'rand' and (dims == 2 or opt.vae_levels <= idx + 1)
-        inp = up + next(noises) * noise_amp[idx + 1] if inject else up
+        inp = up + draw(up.shape) * noise_amp[idx + 1] if inject else up
         x = torch.tanh(_stack7(inp, P, 'body.%d' % idx, opt.num_layer) + up)
     if noise_init is None:
         return x, vae_out, (mu, logvar)

@@ -1,0 +1,206 @@
+"""world_size-2 (and 3) gloo test of the multi-GPU step logic (hp_vae_gan_amd.multigpu.DistStageTrainer) on CPU.
+
+The distributed logic is backend-agnostic; here it is driven with a torch-CPU backend built on the oracle (tests may
+use the oracle) and compared with the single-process oracle train step on the same golden fixture: same losses, and
+post-step G / D parameters equal up to Adam's +-lr sign-flip slack.  Rendezvous on 127.0.0.1."""
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class OracleNet(nn.Module):
+    """torch-CPU network whose forward is the oracle's functional restatement (test-only compute engine)."""
+
+    def __init__(self, sd, opt, dims, kind):
+        super().__init__()
+        from oracle import hpvg_oracle as O
+        self.O, self.opt, self.dims, self.kind = O, opt, dims, kind
+        self.keys = list(sd.keys())
+        for k, v in sd.items():
+            name = k.replace(".", "__")
+            if O.is_param(k):
+                self.register_parameter(name, nn.Parameter(v.clone()))
+            else:
+                self.register_buffer(name, v.clone())
+        self.noise_source = None
+
+    def P(self):
+        return {k: getattr(self, k.replace(".", "__")) for k in self.keys}
+
+    def forward(self, x, noise_amp=None, noise_init=None, sample_init=None, mode="rand"):
+        if self.kind == "D":
+            return self.O.discriminator_forward(x, self.P(), self.opt)
+        src = self.noise_source
+        return self.O.generator_forward(self.P(), self.opt, self.dims, x, noise_amp, noise_init=noise_init, mode=mode,
+                                        noises=lambda shape: src(torch.empty(shape)))
+
+
+class TorchBackend:
+    def __init__(self, opt):
+        self.opt = opt
+        from oracle import hpvg_oracle as O
+        self.O = O
+
+    def mse(self, a, b):
+        return self.O.mse(a, b)
+
+    def kl(self, mu, lv):
+        return self.O.kl_criterion(mu, lv)
+
+    def wgan_mean(self, x, sign):
+        return sign * x.mean()
+
+    def grad_penalty(self, netD, real, fake, lam, alpha):
+        a = alpha.reshape(())
+        xhat = (a * real + (1 - a) * fake).detach().requires_grad_(True)
+        out = netD(xhat)
+        g = torch.autograd.grad(out, xhat, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+        return ((g.norm(2, dim=1) - 1) ** 2).mean() * lam
+
+    def noise(self, ref):
+        return torch.randn(ref.shape)
+
+    def optimizers(self, netG, netD, g_groups, lr_d, beta1):
+        class _O:
+            pass
+        o = _O()
+        gparams = list(netG.parameters())
+        o.optG = torch.optim.Adam([{"params": list(p), "lr": lr} for p, lr in g_groups], betas=(beta1, 0.999))
+
+        def ar(params, group):
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                dist.all_reduce(p.grad, group=group)
+        o.allreduce_G = lambda group=None: ar(gparams, group)
+        o.zero_G = lambda: netG.zero_grad(set_to_none=True)
+
+        def clip_step(max_norm):
+            torch.nn.utils.clip_grad_norm_(gparams, max_norm)
+            o.optG.step()
+        o.clip_step_G = clip_step
+        if netD is not None:
+            dparams = list(netD.parameters())
+            o.optD = torch.optim.Adam(dparams, lr=lr_d, betas=(beta1, 0.999))
+            o.allreduce_D = lambda group=None: ar(dparams, group)
+            o.zero_D = lambda: netD.zero_grad(set_to_none=True)
+            o.step_D = o.optD.step
+        return o
+
+
+def _groups(opt, netG):
+    """Adam groups of the generator as (parameter list, lr), from the oracle's rule table."""
+    from oracle import hpvg_oracle as O
+    named = dict(netG.named_parameters())
+    out = []
+    for prefix, lr in O.g_param_groups(netG.P(), opt, opt.scale_idx):
+        out.append(([p for k, p in named.items() if k.replace("__", ".").startswith(prefix)], lr))
+    return out
+
+
+def _worker(rank, world, port, fname, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from helpers import NoiseFeed, load_golden, opt_from
+    from hp_vae_gan_amd import multigpu
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    opt = opt_from(fx["opt"], scale_idx=fx["scale_idx"], Noise_Amps=list(fx["noise_amps_init"]))
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    dims = fx["dims"]
+    netG = OracleNet(fx["G_init"], opt, dims, "G")
+    netD = OracleNet(fx["D_init"], opt, dims, "D") if fx["D_init"] is not None else None
+    opt.Z_init_size = list(fx["iters"][0]["noise_init"].shape)
+    tr = multigpu.DistStageTrainer(opt, netG, netD, TorchBackend(opt), _groups(opt, netG))
+    rec = fx["iters"][0]
+    gan = netD is not None
+    noises = rec["noises"]
+    if gan:
+        # reference draw order: [calibration eps], rec eps, then the level noises of the rand pass
+        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], "cpu")
+    else:
+        netG.noise_source = NoiseFeed(noises, "cpu")
+        tr._bcast_noise = netG.noise_source  # identical recorded noise on every rank (what the broadcast guarantees)
+    alpha = rec["alpha"] if rec["alpha"] is not None else None
+    out = tr.step(fx["real"], fx["real_zero"], noise_init=rec["noise_init"], alpha=alpha)
+    tr.sync_buffers()
+    if rank < 2:
+        torch.save({"out": {k: v for k, v in out.items()}, "amps": opt.Noise_Amps,
+                    "G": {k: v.detach().clone() for k, v in netG.P().items()},
+                    "D": {k: v.detach().clone() for k, v in netD.P().items()} if gan else None},
+                   os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process(fname):
+    from helpers import load_golden, opt_from, oracle_state
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    PG = oracle_state(fx["G_init"])
+    PD = oracle_state(fx["D_init"]) if fx["D_init"] is not None else None
+    amps = list(fx["noise_amps_init"])
+    rec = fx["iters"][0]
+    noises = iter(rec["noises"])
+    O.noise_amp_for_stage(PG, opt, fx["dims"], fx["scale_idx"], fx["real"], fx["real_zero"], amps, noises)
+    alpha = rec["alpha"].reshape(()) if rec["alpha"] is not None else None
+    out = O.train_step(PG, PD, opt, fx["dims"], fx["scale_idx"], fx["real"], fx["real_zero"], rec["noise_init"], noises, alpha, amps, {}, {})
+    return fx, out, PG, PD, amps
+
+
+@pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step2d_gan_s2.pt", 3), ("step3d_vae_s1.pt", 2)])
+def test_distributed_step_matches_single_process(fname, world):
+    from helpers import assert_close
+    from oracle import hpvg_oracle as O
+    fx, want, PG, PD, amps = _single_process(fname)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), fname, d), nprocs=world, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(2)]
+    lr = fx["opt"]["lr_g"]
+    for r in range(2):
+        assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "errG"):
+            if k in want:
+                assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
+        for k, v in PG.items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        if PD is not None:
+            for k, v in PD.items():
+                if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                    assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    # the two working ranks hold bit-identical replicas after the step
+    for k in got[0]["G"]:
+        if O.is_param(k):
+            assert torch.equal(got[0]["G"][k], got[1]["G"][k]), k
+    if PD is not None:
+        for k in got[0]["D"]:
+            if O.is_param(k):
+                assert torch.equal(got[0]["D"][k], got[1]["D"][k]), k
