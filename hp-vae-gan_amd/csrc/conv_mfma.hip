@@ -102,15 +102,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
   const bool prologue = a.in_scale != nullptr;
   const float* xl = xs + half * KT * PL + l31 + wave * 32;
 
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
   for (int ch = 0; ch < a.nchunk; ++ch) {
     if (ch > 0) __syncthreads();
-    // ---------------- stage CC x KT planes into LDS (zero padded, optional affine+lrelu)
+    if (!prologue) {
+      // ---------------- stage CC x KT planes by LDS-DMA: no VGPR round trip, every load of the chunk in flight at
+      // once; out-of-image lanes read a global zero word, lanes past the plane end are masked off
+#pragma unroll 1
+      for (int pl = 0; pl < CC * KT; ++pl) {
+        const int c = pl / KT, dt = pl - c * KT;
+        const int cg = ch * CC + c;
+        const int tt = t + dt - (KT == 3 ? 1 : 0);
+        const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
+        const float* src = a.x + (((long)b * a.Cin + (valid ? cg : 0)) * a.T + (valid ? tt : 0)) * HW;
+        float* dst = xs + pl * PL + wave * 64;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j)
+          if ((wmask >> j) & 1u)
+            __builtin_amdgcn_global_load_lds((gptr_t)((valid && ((okmask >> j) & 1u)) ? src + gofs[j] : g_zero_word),
+                                             (lptr_t)(dst + j * 256), 4, 0, 0);
+      }
+    } else {
+    // ---------------- stage CC x KT planes into LDS through registers (fused affine + LeakyReLU of the producer)
 #pragma unroll 2
     for (int c = 0; c < CC; ++c) {
       const int cg = ch * CC + c;
       const bool cok = cg < a.Cin;
       float sc = 1.f, sh = 0.f;
-      if (prologue && cok) {
+      if (cok) {
         sc = a.in_scale[cg];
         sh = a.in_shift[cg];
       }
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
         for (int j = 0; j < NJMAX; ++j) {
           if ((wmask >> j) & 1u) {
             float val = v[dt][j];
-            if (prologue && tok && ((okmask >> j) & 1u)) {
+            if (tok && ((okmask >> j) & 1u)) {
               val = val * sc + sh;
               if (a.in_lrelu) val = hpvg_lrelu(val);
             }
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
           }
         }
       }
+    }
     }
     __syncthreads();
 
