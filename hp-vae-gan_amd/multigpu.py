@@ -31,6 +31,46 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged():
+    """gloo cannot move device tensors point-to-point: stage through the host (rehearsal runs of the N>1 path on a
+    one-GPU box use gloo; the real multi-GPU run uses nccl = RCCL and never takes this branch)."""
+    return dist.get_backend() == "gloo"
+
+
+def send(t, dst):
+    if _host_staged() and t.is_cuda:
+        dist.send(t.cpu(), dst=dst)
+    else:
+        dist.send(t, dst=dst)
+
+
+def recv(t, src):
+    if _host_staged() and t.is_cuda:
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src)
+
+
+def all_reduce(t, group=None):
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def broadcast(t, src, group=None):
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 class HipBackend:
     """Losses / optimisers of the product path (gfx950 kernels)."""
 
@@ -62,13 +102,13 @@ class HipBackend:
         o = _Opt()
         o.arenaG = hp_optim.ParamArena(netG)
         o.optG = hp_optim.FlatAdam(o.arenaG, g_groups, betas=(beta1, 0.999))
-        o.allreduce_G = lambda group=None: dist.all_reduce(o.arenaG.grad, group=group)  # ONE collective for all of G
+        o.allreduce_G = lambda group=None: all_reduce(o.arenaG.grad, group=group)  # ONE collective for all of G
         o.zero_G = o.arenaG.zero_grad
         o.clip_step_G = lambda max_norm: (o.arenaG.clip_grad_norm_(max_norm), o.optG.step())
         if netD is not None:
             o.arenaD = hp_optim.ParamArena(netD)
             o.optD = hp_optim.FlatAdam(o.arenaD, [(netD.parameters(), lr_d)], betas=(beta1, 0.999))
-            o.allreduce_D = lambda group=None: dist.all_reduce(o.arenaD.grad, group=group)
+            o.allreduce_D = lambda group=None: all_reduce(o.arenaD.grad, group=group)
             o.zero_D = o.arenaD.zero_grad
             o.step_D = o.optD.step
         return o
@@ -98,12 +138,12 @@ class DistStageTrainer:
     # ---- tiny helpers
     def _bcast_float(self, value, src=0, group=None):
         t = torch.tensor([float(value) if value is not None else 0.0], dtype=torch.float64, device=self.dev)
-        dist.broadcast(t, src=src, group=group)
+        broadcast(t, src=src, group=group)
         return float(t.item())
 
     def _bcast_noise(self, ref):
         n = self.be.noise(ref) if self.rank == 0 else torch.empty_like(ref)
-        dist.broadcast(n, src=0)
+        broadcast(n, src=0)
         return n
 
     def calibrate_noise_amp(self, real, real_zero):
@@ -143,19 +183,19 @@ class DistStageTrainer:
         if r == 0:
             generated, _, _ = netG(real_zero, opt.Noise_Amps, mode="rec")
             fake_b = torch.empty_like(real[0:1])
-            dist.recv(fake_b, src=1)
+            recv(fake_b, src=1)
         else:
             if noise_init is None:
                 noise_init = be.noise(torch.empty(opt.Z_init_size, device=self.dev))
             fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
-            dist.send(fake[0:1].detach().contiguous(), dst=0)
+            send(fake[0:1].detach().contiguous(), dst=0)
             fake_b = fake[1:2].detach().contiguous()
         real_b = real[r:r + 1].contiguous()
         # -- D step on this rank's batch sample (same alpha on both ranks, drawn on rank 0's CPU generator)
         if alpha is None:
             alpha = torch.rand(1, 1) if r == 0 else torch.zeros(1, 1)
         a = alpha.reshape(1).to(self.dev, torch.float32).clone()
-        dist.broadcast(a, src=0, group=g)
+        broadcast(a, src=0, group=g)
         o.zero_D()
         errD_real = be.wgan_mean(netD(real_b), -1.0) * 0.5
         errD_fake = be.wgan_mean(netD(fake_b), 1.0) * 0.5
@@ -173,18 +213,18 @@ class DistStageTrainer:
             p.requires_grad_(True)
         o.zero_G()
         if r == 0:
-            dist.send(dfake_b.contiguous(), dst=1)
+            send(dfake_b.contiguous(), dst=1)
             rec_loss = be.mse(generated, real)
             (opt.rec_weight * rec_loss).backward()
             out["rec_loss"] = rec_loss.detach()
         else:
             dfake0 = torch.empty_like(dfake_b)
-            dist.recv(dfake0, src=0)
+            recv(dfake0, src=0)
             fake.backward(torch.cat([dfake0, dfake_b], dim=0))
         o.allreduce_G(g)
         o.clip_step_G(opt.grad_clip)
         stats = torch.stack([errD_real.detach(), errD_fake.detach(), gp.detach(), errG_b.detach()]).reshape(4).clone()
-        dist.all_reduce(stats, group=g)
+        all_reduce(stats, group=g)
         out.update(errD_real=stats[0], errD_fake=stats[1], gradient_penalty=stats[2], errG=stats[3])
         return out
 
@@ -215,7 +255,7 @@ class DistStageTrainer:
             return
         for b in self.netG.buffers():
             if b.dtype.is_floating_point:
-                dist.all_reduce(b, group=self.pair)
+                all_reduce(b, group=self.pair)
                 b.div_(n)
 
 

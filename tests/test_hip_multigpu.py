@@ -1,0 +1,89 @@
+"""GPU rehearsal of the N>1 path with the real kernels: two processes share the box's single MI355X (gloo rendezvous,
+messages staged through the host) and run hp_vae_gan_amd.multigpu.DistStageTrainer with the HIP backend on a golden
+GAN-stage fixture; both replicas must land on the reference's post-step parameters."""
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fname, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import NoiseFeed, hip_opt, load_golden
+    from hp_vae_gan_amd import multigpu, train as hp_train
+    from hp_vae_gan_amd.modules import networks_2d, networks_3d
+    fx = load_golden(fname)
+    dims, s = fx["dims"], fx["scale_idx"]
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], dims, s, dev)
+    nets = networks_3d if dims == 3 else networks_2d
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(s):
+        netG.init_next_stage()
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    netD = getattr(nets, opt.discriminator)(opt)
+    netD.load_state_dict(fx["D_init"])
+    netD.to(dev)
+    opt.Noise_Amps = list(fx["noise_amps_init"])
+    rec = fx["iters"][0]
+    opt.Z_init_size = list(rec["noise_init"].shape)
+    tr = multigpu.DistStageTrainer(opt, netG, netD, multigpu.HipBackend(opt), hp_train.generator_param_groups(opt, netG))
+    noises = rec["noises"]
+    netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], dev)
+    out = tr.step(fx["real"].to(dev), fx["real_zero"].to(dev), noise_init=rec["noise_init"].to(dev), alpha=rec["alpha"])
+    torch.cuda.synchronize()
+    torch.save({"out": {k: v.cpu() for k, v in out.items()}, "amps": opt.Noise_Amps,
+                "G": {k: v.detach().cpu() for k, v in netG.state_dict().items()},
+                "D": {k: v.detach().cpu() for k, v in netD.state_dict().items()}}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step2d_gan_s2.pt"])
+def test_two_rank_hip_step_matches_reference(fname):
+    from helpers import assert_close, load_golden
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    rec = fx["iters"][0]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), fname, d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(2)]
+    lr = fx["opt"]["lr_g"]
+    for r in range(2):
+        assert got[r]["amps"] == pytest.approx(rec["noise_amps"], rel=1e-4)
+        for k in ("errD_real", "errD_fake", "gradient_penalty"):
+            assert_close(got[r]["out"][k], rec[k], 1e-3, "%s.rank%d.%s" % (fname, r, k))
+        assert_close(got[r]["out"]["errG"], rec["errG"], 3e-3, "%s.rank%d.errG" % (fname, r))
+        for k, v in rec["G_after"].items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-3, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        for k, v in rec["D_after"].items():
+            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                assert_close(got[r]["D"][k], v, 1e-3, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    for k, v in got[0]["G"].items():
+        if O.is_param(k):
+            assert torch.equal(v, got[1]["G"][k]), "replicas diverged: " + k
