@@ -25,6 +25,9 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+# collected separately and committed as profiles/r01_pmc_traffic_stage9.csv; bench.py cannot run the profiler itself.
+MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.095e9}
 
 
 def video_opt(device, **kw):
@@ -251,7 +254,8 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<8,3,2,4> (64->64 3x3x3 fwd, fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "shape": list(key),
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": MEASURED_TRAFFIC_BYTES.get(tuple(key)),
+                    "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 27, "shape": list(key),
                     "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops}
         cpu = None
         if not args.no_cpu_baseline and world == 1:

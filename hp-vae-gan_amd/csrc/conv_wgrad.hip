@@ -398,9 +398,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_narrow_kernel(const NarrowA
 }
 
 // dW from the narrow kernel's fragments; mode 0: dW[o=cw][c=cn][tap]; mode 1: dW[o=cn][c=cw][ntaps-1-tap]
-__global__ void conv_wgrad_narrow_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts, int nwb,
-                                                int NT, int CW, int CN, int taps, int mode, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes stride over the partial slabs, fixed-order shuffle reduction (reproducible)
+__global__ __launch_bounds__(256) void conv_wgrad_narrow_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                         int nparts, int nwb, int NT, int CW, int CN, int taps,
+                                                                         int mode, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int total = CW * CN * taps;
   if (idx >= total) return;
   const int tap = idx % taps;
@@ -413,16 +416,13 @@ __global__ void conv_wgrad_narrow_reduce_kernel(const float* __restrict__ part, 
   const int n = j / 32, col = j % 32;
   const long off = ((long)(wb * 2 * NT) + (m * NT + n)) * 1024 + e * 64 + hf * 32 + col;
   const long pstride = (long)nwb * 2 * NT * 1024;
-  float s0 = 0.f, s1 = 0.f;
-  int p = 0;
-  for (; p + 2 <= nparts; p += 2) {
-    s0 += part[(long)p * pstride + off];
-    s1 += part[(long)(p + 1) * pstride + off];
+  float s = 0.f;
+  for (int p = lane; p < nparts; p += 64) s += part[(long)p * pstride + off];
+  const float tot = hpvg_wave_sum(s);
+  if (lane == 0) {
+    float* dst = mode == 0 ? dw + ((long)cw * CN + cn) * taps + tap : dw + ((long)cn * CW + cw) * taps + (taps - 1 - tap);
+    *dst = accumulate ? *dst + tot : tot;
   }
-  if (p < nparts) s0 += part[(long)p * pstride + off];
-  const float tot = s0 + s1;
-  float* dst = mode == 0 ? dw + ((long)cw * CN + cn) * taps + tap : dw + ((long)cn * CW + cw) * taps + (taps - 1 - tap);
-  *dst = accumulate ? *dst + tot : tot;
 }
 
 // dW[o][c][dt][tap9] = sum_s part[s][dt][z][tap9][o%64][c%64]; one thread per slab element, fixed order.
@@ -602,7 +602,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
     int st = hpvg_launch_status();
     if (st != HPVG_OK) return st;
     const int total = CW * CN * KT * 9;
-    hipLaunchKernelGGL(conv_wgrad_narrow_reduce_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, s, (const float*)na.part, dw,
+    hipLaunchKernelGGL(conv_wgrad_narrow_reduce_kernel, dim3(hpvg_cdiv(total, 4)), dim3(256), 0, s, (const float*)na.part, dw,
                        (int)S * 4, nwb, NT, CW, CN, KT * 9, nm, accumulate);
     return hpvg_launch_status();
   }
