@@ -454,7 +454,11 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipel
   const int mbtot = hpvg_cdiv(Cout, 32);
   Plan best{};
   double best_cost = 1e300;
+  // development knobs: restrict the search to one NB / MB
+  static const int only_nb = [] { const char* e = getenv("HPVG_PLAN_NB"); return e ? atoi(e) : 0; }();
+  static const int only_mb = [] { const char* e = getenv("HPVG_PLAN_MB"); return e ? atoi(e) : 0; }();
   for (int MB = (mbtot >= 2 ? 2 : 1); MB >= 1; --MB) {
+    if (only_mb && MB != only_mb && mbtot >= 2) continue;
     const int gridy = hpvg_cdiv(mbtot, MB);
     for (int Tw = 1; Tw <= W; ++Tw) {
       const int ntw = hpvg_cdiv(W, Tw);
@@ -469,6 +473,7 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipel
         if ((Th + 2) * RS > NJMAX * 256) break;
         const int rounds = hpvg_cdiv(nblocks, 4);
         const int NB = rounds <= 1 ? 1 : (rounds == 2 ? 2 : 4);
+        if (only_nb && NB != only_nb) continue;
         int PL = (Th + 2) * RS;
         const int need = 128 * NB + 2 * RS + 2;
         if (PL < need) PL = need;

@@ -120,3 +120,37 @@ def test_compute_on_cpu_fails_loudly():
         D(torch.zeros(1, 3, 2, 4, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.MSE.apply(torch.zeros(4), torch.zeros(4))
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    """Reference-format checkpoint files: keys, resume rule, D warm start (host logic only, CPU)."""
+    from hp_vae_gan_amd import checkpoint as ck
+    fx = load_golden("step3d_gan_s3.pt")
+    opt = opt_from(fx["opt"], scale_idx=3, Noise_Amps=[1, 0.05, 0.06, 0.07])
+    G = networks_3d.GeneratorHPVAEGAN(opt)
+    for _ in range(3):
+        G.init_next_stage()
+    G.load_state_dict(fx["G_init"])
+    D = networks_3d.WDiscriminator3D(opt)
+    D.load_state_dict(fx["D_init"])
+
+    class _Opt:
+        def state_dict(self):
+            return {"t": 0}
+
+    class _Tr:
+        netG, netD, optimizerG, optimizerD = G, D, _Opt(), _Opt()
+    files = ck.stage_checkpoint(opt, _Tr)
+    assert set(files) == {"Noise_Amps.pth", "netG.pth", "netD_3.pth"}
+    assert set(files["netG.pth"]) == {"scale", "state_dict", "optimizer", "noise_amps"}
+    assert set(files["netD_3.pth"]) == {"scale", "state_dict", "optimizer"}
+    assert list(files["netG.pth"]["state_dict"].keys()) == list(fx["G_init"].keys())
+    ck.save_stage(str(tmp_path), opt, _Tr)
+    G2 = networks_3d.GeneratorHPVAEGAN(opt)
+    scale, amps = ck.resume_generator(G2, str(tmp_path))
+    assert scale == 3 and amps == [1, 0.05, 0.06, 0.07] and len(G2.body) == 3
+    for k, v in G2.state_dict().items():
+        assert torch.equal(v, fx["G_init"][k]), k
+    D2 = ck.warm_start_discriminator(networks_3d.WDiscriminator3D(opt), str(tmp_path), 4)
+    for k, v in D2.state_dict().items():
+        assert torch.equal(v, fx["D_init"][k]), k

@@ -170,3 +170,30 @@ def test_train_step(fname):
         if rec["D_after"] is not None:
             for k, v in rec["D_after"].items():
                 assert_close(PD[k].float(), v.float(), 1e-4, fname + ".D_after." + k, atol=2 * lr)
+
+
+def test_c_restatement_of_conv_matches():
+    """oracle/conv_direct.c (plain C loops) against the oracle's torch conv on small 3-D and 2-D cases."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(GOLDEN.rstrip("/").rsplit("/tests", 1)[0] + "/x")
+    so = os.path.join(root, "oracle", "libconv_direct.so")
+    src = os.path.join(root, "oracle", "conv_direct.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src, "-lm"])
+    lib = ctypes.CDLL(so)
+    fp = ctypes.POINTER(ctypes.c_float)
+    torch.manual_seed(1)
+    for shape, KT in (((2, 3, 3, 4, 5), 3), ((1, 5, 2, 3, 7), 3), ((2, 4, 6, 5), 1)):
+        Cin = shape[1]
+        Cout = 6
+        x = torch.randn(*shape)
+        w = torch.randn(Cout, Cin, *([3] * (len(shape) - 2)))
+        b = torch.randn(Cout)
+        want = O.conv(x, w, b)
+        y = torch.empty_like(want)
+        T = shape[2] if KT == 3 else 1
+        H, W = shape[-2], shape[-1]
+        lib.hpvg_oracle_conv_direct(x.contiguous().data_ptr() and ctypes.cast(x.data_ptr(), fp), ctypes.cast(w.data_ptr(), fp),
+                                    ctypes.cast(b.data_ptr(), fp), ctypes.cast(y.data_ptr(), fp), shape[0], Cin, Cout, T, H, W, KT)
+        assert_close(y, want, 1e-5, "conv_direct.c")
