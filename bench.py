@@ -30,7 +30,27 @@ PEAK_HBM_GBS = 8000.0
 MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.095e9}
 
 
+CONFIG = "video"  # set by --config: "video" = BASELINE configs[2] (metric config), "image" = configs[1] (2-D path)
+
+
 def video_opt(device, **kw):
+    if CONFIG == "image":
+        return image_opt(device, **kw)
+    return _video_opt(device, **kw)
+
+
+def image_opt(device, **kw):
+    """BASELINE configs[1]: train_image.py air_balloons.jpg (248x186 -> ar 0.75), --vae-levels 3, 2-D conv path."""
+    o = _video_opt(device, **kw)
+    o.dims = 2
+    o.ar = 186.0 / 248.0
+    o.discriminator = "WDiscriminator2D"
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _video_opt(device, **kw):
     o = types.SimpleNamespace(
         dims=3, nc_im=3, nfc=64, latent_dim=128, enc_blocks=2, ker_size=3, num_layer=5, padd_size=1, stride=1,
         vae_levels=3, train_all=False, train_depth=1, scale_factor_init=0.75, min_size=32, max_size=256, img_size=256,
@@ -58,18 +78,18 @@ class _HipGeom:
     @staticmethod
     def level_shape(i, opt):
         from hp_vae_gan_amd import utils as hu
-        return hu.images.level_shape_3d(i, opt)
+        return hu.images.level_shape_3d(i, opt) if opt.dims == 3 else hu.images.level_shape_2d(i, opt)
 
 
 def build_gpu_stages(device, stages):
     """One StageTrainer per pyramid stage with synthetic resident inputs (setup is outside the timed region)."""
     import copy
     from hp_vae_gan_amd import train as hp_train
-    from hp_vae_gan_amd.modules import networks_3d
+    from hp_vae_gan_amd.modules import networks_2d, networks_3d
     torch.manual_seed(0)
     base = video_opt(device)
     shapes = stage_shapes(base, _HipGeom)
-    proto = networks_3d.GeneratorHPVAEGAN(base)
+    proto = (networks_3d if base.dims == 3 else networks_2d).GeneratorHPVAEGAN(base)
     out = []
     for s in range(base.stop_scale + 1):
         if s > 0:
@@ -163,13 +183,20 @@ def main():
     ap.add_argument("--stages", type=str, default="0-9", help="pyramid stages in a step, e.g. 0-9 or 9")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stages", type=str, default="0-5")
+    ap.add_argument("--config", choices=["video", "image"], default="video",
+                    help="video = BASELINE configs[2] (the metric's config, default); image = configs[1] (2-D path)")
     args = ap.parse_args()
+    global CONFIG
+    CONFIG = args.config
 
     def parse(r):
         a, _, b = r.partition("-")
         return list(range(int(a), int(b or a) + 1))
 
     stages = parse(args.stages)
+    # keep torch's CPU thread pool small: the host side only launches kernels; a 128-thread OpenMP pool spinning after
+    # tiny CPU ops exhausts the box's CPU share and the launching thread gets throttled for ~75 ms at a time
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,24 +243,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        runner.step()
+    # Stage-major order, as training proceeds (train_video.py:414-417: each stage runs its iterations before the next
+    # stage starts): W warm-up then K timed iterations of every stage = K "steps" of one iteration per stage.
+    for i in range(runner.n):
+        for _ in range(args.warmup):
+            runner.timed_stage(i)
     barrier()
     # ---- timed region: exactly K steps; the dominant kernel's launches are bracketed by HIP events on the launch stream
-    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == 3 and not g["flip"])
+    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == (3 if CONFIG == "video" else 1) and not g["flip"])
     ops.set_kernel_timer(timer)
     stage_ev = {}
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        for i in range(runner.n):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+    for i in range(runner.n):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(args.steps):
             s = runner.timed_stage(i)
-            e1.record()
-            stage_ev.setdefault(s, []).append((e0, e1))
+        e1.record()
+        stage_ev[s] = (e0, e1)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     ops.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -242,7 +276,7 @@ def main():
 
     if rank == 0:
         nstage = len(stages)
-        per_stage = {str(s): (1000.0 / (sum(a.elapsed_time(b) for a, b in ev) / len(ev))) for s, ev in stage_ev.items()}
+        per_stage = {str(s): 1000.0 * args.steps / ev[0].elapsed_time(ev[1]) for s, ev in stage_ev.items()}
         # dominant kernel: the 64->64 3x3x3 implicit-GEMM conv at the finest resident stage
         roof = None
         by_shape = timer.summary()
@@ -250,7 +284,7 @@ def main():
             key = max(by_shape, key=lambda k: k[2] * k[3] * k[4])
             ms, n = by_shape[key]
             B, C, T, H, W = key
-            flops = 2.0 * B * 64 * 64 * 27 * T * H * W
+            flops = 2.0 * B * 64 * 64 * (27 if CONFIG == "video" else 9) * T * H * W
             achieved = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<8,3,2,4> (64->64 3x3x3 fwd, fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -258,7 +292,7 @@ def main():
                     "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 27, "shape": list(key),
                     "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops}
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and CONFIG == "video":
             cs = [s for s in parse(args.cpu_stages) if s in stages]
             if cs:
                 threads = min(os.cpu_count() or 1, 16)
@@ -275,7 +309,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2]); "
+            "config": {"workload": ("train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2]); "
+                                    if CONFIG == "video" else
+                                    "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path); ") +
                                    "step = 1 train iteration at each pyramid stage %s" % args.stages,
                        "stages": stages, "parallelism": "single GPU" if world == 1 else "rec/rand generator passes on ranks 0/1 + discriminator work split over the batch (2 working ranks of %d)" % world},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},

@@ -449,7 +449,7 @@ struct Plan {
 };
 
 // Tile planner: minimise (waves of workgroups over the chip) x (per-workgroup MFMA rounds).
-Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
+Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
   const int CC = conv_cc(Cin);
   const int mbtot = hpvg_cdiv(Cout, 32);
   Plan best{};
@@ -504,6 +504,23 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipel
     }
   }
   return best;
+}
+
+// The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).
+Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
+  struct Key { int B, Cin, Cout, T, H, W, KT, pipe; };
+  struct Entry { Key k; Plan p; };
+  static thread_local Entry cache[128];
+  static thread_local int used = 0;
+  const Key k{B, Cin, Cout, T, H, W, KT, pipelined ? 1 : 0};
+  for (int i = 0; i < used; ++i) {
+    const Key& c = cache[i].k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.pipe == k.pipe)
+      return cache[i].p;
+  }
+  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, pipelined);
+  if (used < 128) cache[used++] = Entry{k, p};
+  return p;
 }
 
 template <int CC, int KT, int MB, int NB>

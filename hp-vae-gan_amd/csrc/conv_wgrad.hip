@@ -488,7 +488,7 @@ struct WPlan {
   size_t lds;
 };
 
-WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   WPlan best{};
   double best_cost = 1e300;
   const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
@@ -523,6 +523,20 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
     best.S = (int)(ntiles < cap ? ntiles : cap);
   }
   return best;
+}
+
+WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  struct Key { int B, Cin, Cout, T, H, W, KT; };
+  struct Entry { Key k; WPlan p; };
+  static thread_local Entry cache[128];
+  static thread_local int used = 0;
+  for (int i = 0; i < used; ++i) {
+    const Key& c = cache[i].k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return cache[i].p;
+  }
+  const WPlan p = plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
+  if (used < 128) cache[used++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
+  return p;
 }
 
 // narrow path selection: 0 = head (Cin <= 4), 1 = tail (Cout <= 4), -1 = full kernel

@@ -63,7 +63,7 @@ def generate_noise(ref=None, size=None, type='normal', emb_size=None, device=Non
     if ref is not None:
         noise = torch.zeros_like(ref)
     elif size is not None:
-        noise = torch.zeros(*size).to(device)
+        noise = torch.zeros(*size, device=device)  # allocated on the target device (no host tensor, no H2D copy)
     else:
         raise Exception("ref or size must be applied")
 
