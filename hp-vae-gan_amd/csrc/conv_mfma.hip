@@ -171,28 +171,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
     AVec av[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) av[m] = wpt[m * 64];
+    // B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (two register sets; CP is even, so the
+    // parity is static); past the chunk's last k-step this is a harmless in-buffer read.
+    float bv[2][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bv[0][i] = xl[i * 128];
 #pragma unroll 1
     for (int dt = 0; dt < KT; ++dt) {
 #pragma unroll
       for (int dh = 0; dh < 3; ++dh) {
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) {
-          // prefetch the next tap's A fragments (the pack has one tap of tail padding)
+          // prefetch the next tap's A fragments (the pack has tail padding)
           wpt += (long)a.mbtot * 64;
           AVec an[MB];
 #pragma unroll
           for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
           const float* xt = xl + dt * PL + dh * RS + dw;
+          const float* xn = (dw < 2) ? xt + 1 : (dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1 < KT ? dt + 1 : 0) * PL);
 #pragma unroll
           for (int cp = 0; cp < CP; ++cp) {
-            float bv[NB];
+            const float* nx = (cp + 1 < CP) ? xt + (2 * (cp + 1) * KT) * PL : xn;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bv[i] = xt[(2 * cp * KT) * PL + i * 128];
+            for (int i = 0; i < NB; ++i) bv[(cp + 1) & 1][i] = nx[i * 128];
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this k-step's MFMAs
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
               for (int m = 0; m < MB; ++m)
-                acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[i], acc[m][i], 0, 0, 0);
+                acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[cp & 1][i], acc[m][i], 0, 0, 0);
           }
 #pragma unroll
           for (int m = 0; m < MB; ++m) av[m] = an[m];
