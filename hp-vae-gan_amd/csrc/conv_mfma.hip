@@ -195,11 +195,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
 #pragma unroll
             for (int i = 0; i < NB; ++i) bv[(cp + 1) & 1][i] = nx[i * 128];
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this k-step's MFMAs
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
               for (int m = 0; m < MB; ++m)
                 acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[cp & 1][i], acc[m][i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
           }
 #pragma unroll
           for (int m = 0; m < MB; ++m) av[m] = an[m];
@@ -210,6 +212,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
 
   // ---------------- epilogue: bias, optional LeakyReLU, masked store
   // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float bias_r[MB][16];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      bias_r[m][e] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int blk = wave + 4 * i;
@@ -225,8 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       for (int e = 0; e < 16; ++e) {
         const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (co < a.Cout) {
-          float val = acc[m][i][e];
-          if (a.bias) val += a.bias[co];
+          float val = acc[m][i][e] + bias_r[m][e];
           if (a.out_lrelu) val = hpvg_lrelu(val);
           a.y[((long)b * a.Cout + co) * a.T * HW + sp] = val;
         }
