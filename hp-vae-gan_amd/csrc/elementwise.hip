@@ -272,6 +272,11 @@ __global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restric
   const float v = g[0] * coef;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v;
 }
+// out = a + b
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
 // out = x / s[0]   (spectral norm: weight = weight_orig / sigma)
 __global__ __launch_bounds__(256) void div_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                           float* __restrict__ out, long n) {
@@ -637,6 +642,12 @@ int hpvg_sqsum_f32(const float* x, float* out, void* ws, size_t ws_bytes, long n
 int hpvg_fill_scaled_f32(const float* gout, float coef, float* out, long n, void* stream) {
   if (!gout || !out || n < 1) return HPVG_ERR_ARG;
   hipLaunchKernelGGL(fill_scaled_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gout, coef, out, n);
+  return hpvg_launch_status();
+}
+// out = a + b
+int hpvg_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
+  if (!a || !b || !out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
   return hpvg_launch_status();
 }
 // out = x / s[0]   (s: device scalar)

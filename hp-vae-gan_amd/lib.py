@@ -41,6 +41,7 @@ _SIGS = {
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
     "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, P, P, P, P, Z, I, I, L, P],
     "hpvg_lrelu_mask_mul_f32": [P, P, P, L, P],
+    "hpvg_add_f32": [P, P, P, L, P],
     "hpvg_tanh_fwd_f32": [P, P, P, L, P],
     "hpvg_tanh_bwd_f32": [P, P, P, L, P],
     "hpvg_reparam_fwd_f32": [P, P, P, P, L, P],

@@ -25,9 +25,10 @@ class Conv(nn.Module):
 
     def __init__(self, dims, in_channel, out_channel, ker_size=3, padding=1, stride=1):
         super().__init__()
-        if ker_size != 3 or padding != 1 or stride != 1:
-            raise NotImplementedError("the MI355X path implements ker_size=3, padding=1, stride=1 (reference defaults)")
+        if ker_size != 3 or padding not in (0, 1) or stride != 1:
+            raise NotImplementedError("the MI355X path implements ker_size=3, padding in {0, 1}, stride=1")
         self.dims = dims
+        self.padding = padding
         self.weight = nn.Parameter(torch.empty(out_channel, in_channel, *_kernel_shape(dims)))
         self.bias = nn.Parameter(torch.empty(out_channel))
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -36,7 +37,16 @@ class Conv(nn.Module):
         init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x, act=False):
-        return ops.Conv.apply(x, self.weight, self.bias, act)
+        y = ops.Conv.apply(x, self.weight, self.bias, act)
+        return y if self.padding == 1 else crop_border(y)
+
+
+def crop_border(y):
+    """padding=0 ("valid") convolution of the SinGAN baselines (networks_3d.py:285-290) = the zero-padded conv with
+    its outermost voxel shell removed (every kept output only ever saw real inputs).  Pure data movement (torch
+    slicing; autograd's backward of it is the zero pad that the backward-data pass needs)."""
+    idx = (slice(None), slice(None)) + (slice(1, -1),) * (y.dim() - 2)
+    return y[idx].contiguous()
 
 
 class SNConv(nn.Module):
@@ -267,3 +277,59 @@ class GeneratorHPVAEGAN(nn.Module):
                 x_prev = block(up)
             x_prev_out = ops.TanhRes.apply(x_prev, up)
         return x_prev_out
+
+
+def weights_init(m):
+    """N(0, 0.02) conv weights, N(1, 0.02) BatchNorm scale, zero BatchNorm shift (reference: networks_3d.py:9-15;
+    applied to the SinGAN baselines only)."""
+    if isinstance(m, Conv):
+        m.weight.data.normal_(0.0, 0.02)
+    elif isinstance(m, BatchNorm):
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+class GeneratorSG(nn.Module):
+    """SinGAN-3D baseline generator (reference: networks_3d.py:272-322, BASELINE config 5): every stage is a 7-conv
+    stack of VALID convolutions on a volume padded by num_layer+2 = 7 voxels per side; stage 0 maps noise to video,
+    stage k >= 1 refines the upsampled previous output (rand: the previous output is resized straight to the padded
+    size and noise is added; rec: zero padding).  `noise_source` as in GeneratorHPVAEGAN."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        N = int(opt.nfc)
+        self.pad = opt.num_layer + 2
+        self.body = nn.ModuleList([])
+        first = nn.Sequential()
+        first.add_module('head', ConvBlock(3, opt.nc_im, N, opt.ker_size, 0, 1))
+        for i in range(opt.num_layer):
+            first.add_module('block%d' % i, ConvBlock(3, N, N, opt.ker_size, 0, 1))
+        first.add_module('tail', Conv(3, N, opt.nc_im, opt.ker_size, 0, 1))
+        self.body.append(first)
+        self.apply(weights_init)
+        self.noise_source = None
+
+    def init_next_stage(self):
+        self.body.append(copy.deepcopy(self.body[-1]))
+
+    def _zero_pad(self, x):
+        p = self.pad
+        return torch.nn.functional.pad(x, (p, p, p, p, p, p))
+
+    def forward(self, noise_init, noise_amp, mode='rand'):
+        x_prev_out = self.body[0](self._zero_pad(noise_init))
+        for idx, block in enumerate(self.body[1:], 1):
+            x_prev_out = ops.TanhRes.apply(x_prev_out, None)
+            size = hp_utils.images.level_shape_3d(idx, self.opt)
+            up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
+            if mode == 'rand':
+                big = tuple(s + 2 * self.pad for s in size)
+                ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
+                noise = self.noise_source(ref) if self.noise_source is not None else hp_utils.generate_noise(ref=ref)
+                _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, noise, float(noise_amp[idx]))
+                x_prev = block(up2_noisy)
+            else:
+                x_prev = block(self._zero_pad(up))
+            x_prev_out = ops.Add.apply(x_prev, up)
+        return ops.TanhRes.apply(x_prev_out, None)

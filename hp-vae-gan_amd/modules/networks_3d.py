@@ -4,7 +4,9 @@ from . import _nets
 from .. import ops
 
 __all__ = ['ConvBlock3D', 'ConvBlock3DSN', 'FeatureExtractor', 'Encode3DVAE', 'WDiscriminator3D', 'GeneratorHPVAEGAN',
-           'reparameterize']
+           'GeneratorSG', 'weights_init', 'reparameterize']
+
+weights_init = _nets.weights_init
 
 
 def reparameterize(mu, logvar, training, eps=None):
@@ -44,3 +46,7 @@ class WDiscriminator3D(_nets.WDiscriminator):
 class GeneratorHPVAEGAN(_nets.GeneratorHPVAEGAN):
     def __init__(self, opt):
         super().__init__(3, opt)
+
+
+class GeneratorSG(_nets.GeneratorSG):
+    """SinGAN-3D baseline (BASELINE config 5; reference: networks_3d.py:272-322)."""

@@ -355,6 +355,23 @@ class TanhRes(Function):
         return dx, (dx if ctx.has_res else None)
 
 
+class Add(Function):
+    """a + b: the pre-tanh residual of the SinGAN baseline (networks_3d.py:319)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty_like(a)
+        call("hpvg_add_f32", ptr(a), ptr(b), ptr(out), ctypes.c_long(a.numel()), stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class UpsampleAC(Function):
     """Tri/bi-linear resize with align_corners=True to `size`; with `noise`, also returns up + amp*noise
     (utils/images.py:83-105 + networks_3d.py:395-400)."""

@@ -162,3 +162,82 @@ def train(opt, netG, data, netD=None, niter=None):
             real_zero = real
         trainer.step(real, real_zero)
     return trainer
+
+
+class BaselineStageTrainer:
+    """One pyramid stage of the SinGAN-3D baseline trainer (reference: train_video_baselines.py:24-213, BASELINE
+    config 5): fixed reconstruction noise `opt.Z_init`, older stages frozen (requires_grad=False), `Dsteps`
+    discriminator updates (the generator graph is kept only for the last one), then the adversarial + alpha * MSE
+    generator loss and `Gsteps` optimizer steps; no gradient clipping.  Quirk kept: the iteration-0 noise-amplitude
+    pass runs WITH autograd enabled (train_video_baselines.py:117-122)."""
+
+    def __init__(self, opt, netG, netD=None):
+        self.opt, self.netG = opt, netG
+        nets = _networks(opt)
+        if not hasattr(opt, 'Z_init'):
+            level0 = utils.images.level_shape_3d(0, opt)
+            opt.Z_init = utils.generate_noise(size=[opt.batch_size, 3, *level0], device=opt.device)
+        self.netD = netD if netD is not None else getattr(nets, opt.discriminator)(opt).to(opt.device)
+        for block in netG.body[:-opt.train_depth]:
+            for p in block.parameters():
+                p.requires_grad = False
+        blocks = list(netG.body[-opt.train_depth:])
+        groups = [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, b in enumerate(blocks)]
+        self.arenaD = hp_optim.ParamArena(self.netD)
+        self.optimizerD = hp_optim.FlatAdam(self.arenaD, [(self.netD.parameters(), opt.lr_d)], betas=(opt.beta1, 0.999))
+        self.arenaG = hp_optim.ParamArena(netG)
+        self.optimizerG = hp_optim.FlatAdam(self.arenaG, groups, betas=(opt.beta1, 0.999))
+        self.iteration = 0
+
+    def step(self, real, noise_init=None, alphas=None):
+        opt, netG, netD = self.opt, self.netG, self.netD
+        if noise_init is None:
+            noise_init = utils.generate_noise(ref=opt.Z_init)
+        if self.iteration == 0:
+            if opt.scale_idx == 0:
+                opt.noise_amp = 1
+                opt.Noise_Amps.append(opt.noise_amp)
+            else:
+                opt.Noise_Amps.append(0)
+                z_reconstruction = netG(opt.Z_init, opt.Noise_Amps, mode="rec")
+                rmse = torch.sqrt(mse_loss(real, z_reconstruction))
+                opt.noise_amp = opt.noise_amp_init * rmse.item() / opt.batch_size
+                opt.Noise_Amps[-1] = opt.noise_amp
+        out = {}
+        for j in range(opt.Dsteps):
+            self.arenaD.zero_grad()
+            errD_real = wgan_mean(netD(real), -1.0)
+            if j == opt.Dsteps - 1:
+                fake = netG(noise_init, opt.Noise_Amps, mode="rand")
+            else:
+                with torch.no_grad():
+                    fake = netG(noise_init, opt.Noise_Amps, mode="rand")
+            errD_fake = wgan_mean(netD(fake.detach()), 1.0)
+            gradient_penalty = calc_gradient_penalty(netD, real, fake, opt.lambda_grad, opt.device,
+                                                     alpha=None if alphas is None else alphas[j])
+            (errD_real + errD_fake + gradient_penalty).backward()
+            if getattr(opt, 'record_grads', False):
+                out['gradD_flat'] = self.arenaD.grad.clone()
+            self.optimizerD.step()
+        for p in netD.parameters():
+            p.requires_grad_(False)
+        errG = wgan_mean(netD(fake), -1.0) * opt.disc_loss_weight
+        for p in netD.parameters():
+            p.requires_grad_(True)
+        errG_total = errG
+        generated = None
+        if opt.alpha > 0:
+            generated = netG(opt.Z_init, opt.Noise_Amps, mode="rec")
+            rec_loss = opt.alpha * mse_loss(generated, real)
+            errG_total = errG_total + rec_loss
+            out['rec_loss'] = rec_loss.detach()
+        self.arenaG.zero_grad()
+        errG_total.backward()
+        if getattr(opt, 'record_grads', False):
+            out['gradG_flat'] = self.arenaG.grad.clone()
+        for _ in range(opt.Gsteps):
+            self.optimizerG.step()
+        self.iteration += 1
+        out.update(errD_real=errD_real.detach(), errD_fake=errD_fake.detach(), gradient_penalty=gradient_penalty.detach(),
+                   errG=errG.detach(), fake=fake.detach(), generated=None if generated is None else generated.detach())
+        return out

@@ -178,6 +178,89 @@ def _bn_block(x, P, prefix):
     return leaky_relu(y)
 
 
+def conv_valid(x, w, b=None):
+    """padding=0 convolution of the SinGAN baselines (networks_3d.py:285-290)."""
+    return F.conv3d(x, w, b, stride=1, padding=0)
+
+
+def _bn_block_valid(x, P, prefix):
+    r = conv_valid(x, P[prefix + '.conv.weight'], P[prefix + '.conv.bias'])
+    if prefix + '.norm.num_batches_tracked' in P:
+        P[prefix + '.norm.num_batches_tracked'] += 1
+    return leaky_relu(batch_norm_train(r, P[prefix + '.norm.weight'], P[prefix + '.norm.bias'], P[prefix + '.norm.running_mean'],
+                                       P[prefix + '.norm.running_var']))
+
+
+def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None):
+    """GeneratorSG.forward (networks_3d.py:298-322): valid 7-conv stacks on volumes padded by num_layer+2."""
+    pad = opt.num_layer + 2
+    p6 = (pad,) * 6
+
+    def stack(x, k):
+        h = _bn_block_valid(x, P, 'body.%d.head' % k)
+        for i in range(opt.num_layer):
+            h = _bn_block_valid(h, P, 'body.%d.block%d' % (k, i))
+        return conv_valid(h, P['body.%d.tail.weight' % k], P['body.%d.tail.bias' % k])
+
+    x = stack(F.pad(noise_init, p6), 0)
+    for idx in range(1, num_body(P)):
+        x = torch.tanh(x)
+        size = level_shape(idx, opt, 3)
+        up = resize_linear_ac(x, size)
+        if mode == 'rand':
+            up2 = resize_linear_ac(x, [s_ + 2 * pad for s_ in size])
+            nz = noises(tuple(up2.shape)) if callable(noises) else next(noises)
+            xp = stack(up2 + nz * noise_amp[idx], idx)
+        else:
+            xp = stack(F.pad(up, p6), idx)
+        x = xp + up
+    return torch.tanh(x)
+
+
+def baseline_train_step(PG, PD, opt, scale_idx, real, Z_init, noise_init, noises, alphas, noise_amps, adam_g, adam_d):
+    """One iteration of the baseline train() (train_video_baselines.py:93-173) with all random draws injected."""
+    out = {}
+    nb = num_body(PG)
+    trained = ['body.%d.' % k for k in range(nb)][-opt.train_depth:]
+    gparams = {k: v for k, v in PG.items() if is_param(k) and any(k.startswith(t) for t in trained)}
+    dparams = {k: v for k, v in PD.items() if is_param(k)}
+    for j in range(opt.Dsteps):
+        errD_real = -discriminator_forward(real, PD, opt).mean()
+        if j == opt.Dsteps - 1:
+            fake = generator_sg_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
+        else:
+            with torch.no_grad():
+                fake = generator_sg_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
+        errD_fake = discriminator_forward(fake.detach(), PD, opt).mean()
+        gp = gradient_penalty(PD, opt, real, fake, opt.lambda_grad, alphas[j])
+        dgrads = torch.autograd.grad(errD_real + errD_fake + gp, list(dparams.values()), allow_unused=True)
+        out['gradsD'] = {k: (g.clone() if g is not None else None) for k, g in zip(dparams.keys(), dgrads)}
+        for (k, p), g in zip(dparams.items(), dgrads):
+            if g is not None:
+                with torch.no_grad():
+                    adam_step(p, g, adam_d.setdefault(k, {}), opt.lr_d, opt.beta1)
+    errG = -discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
+    total = errG
+    if opt.alpha > 0:
+        generated = generator_sg_forward(PG, opt, Z_init, noise_amps, 'rec', None)
+        rec_loss = opt.alpha * mse(generated, real)
+        total = total + rec_loss
+        out['rec_loss'] = rec_loss.detach()
+    keys = list(gparams.keys())
+    grads = torch.autograd.grad(total, [gparams[k] for k in keys], allow_unused=True)
+    out['gradsG'] = {k: (g.clone() if g is not None else None) for k, g in zip(keys, grads)}
+    blocks = list(range(nb))[-opt.train_depth:]
+    for i, kb in enumerate(blocks):
+        lr = opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))
+        for k, g in zip(keys, grads):
+            if k.startswith('body.%d.' % kb) and g is not None:
+                for _ in range(opt.Gsteps):
+                    with torch.no_grad():
+                        adam_step(gparams[k], g, adam_g.setdefault(k, {}), lr, opt.beta1)
+    out.update(errD_real=errD_real.detach(), errD_fake=errD_fake.detach(), gradient_penalty=gp.detach(), errG=errG.detach())
+    return out
+
+
 def _stack7(x, P, prefix, num_layer):
     h = _bn_block(x, P, prefix + '.head')
     for i in range(num_layer):

@@ -210,6 +210,78 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
     return fx
 
 
+def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed):
+    """train_video_baselines.py:93-173 driven around the reference's GeneratorSG / WDiscriminator3D."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    images.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    netG = n3.GeneratorSG(opt)
+    for _ in range(scale_idx):
+        netG.init_next_stage()
+    perturb(netG, gen)
+    D = n3.WDiscriminator3D(opt)
+    perturb(D, gen)
+    optimizerD = optim.Adam(D.parameters(), lr=opt.lr_d, betas=(opt.beta1, 0.999))
+    for block in netG.body[:-opt.train_depth]:
+        for p in block.parameters():
+            p.requires_grad = False
+    blocks = netG.body[-opt.train_depth:]
+    optimizerG = optim.Adam([{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))}
+                             for i, b in enumerate(blocks)], lr=opt.lr_g, betas=(opt.beta1, 0.999))
+
+    def shape(i):
+        w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+        _, td, _ = images.get_fps_td_by_index(i, opt)
+        return [td, int(w * opt.ar), w]
+
+    real = torch.rand(opt.batch_size, 3, *shape(scale_idx), generator=gen) * 2 - 1
+    Z_init = torch.randn(opt.batch_size, 3, *shape(0), generator=gen)
+    noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx)]
+    rec_loss_fn = torch.nn.MSELoss()
+    fx = {'opt': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, bool, list, str))}, 'scale_idx': scale_idx,
+          'real': real, 'Z_init': Z_init, 'G_init': sd_clone(netG), 'D_init': sd_clone(D), 'noise_amps_init': list(noise_amps),
+          'iters': []}
+    for it in range(n_iters):
+        with Recorder() as rec:
+            noise_init = images.generate_noise(ref=Z_init)
+            if it == 0:
+                if scale_idx == 0:
+                    noise_amps.append(1)
+                else:
+                    noise_amps.append(0)
+                    z_rec = netG(Z_init, noise_amps, mode="rec")
+                    rmse = torch.sqrt(F.mse_loss(real, z_rec))
+                    noise_amps[-1] = opt.noise_amp_init * rmse.item() / opt.batch_size
+            for j in range(opt.Dsteps):
+                D.zero_grad()
+                errD_real = -D(real).mean()
+                if j == opt.Dsteps - 1:
+                    fake = netG(noise_init, noise_amps, mode="rand")
+                else:
+                    with torch.no_grad():
+                        fake = netG(noise_init, noise_amps, mode="rand")
+                errD_fake = D(fake.detach()).mean()
+                gp = mutils.calc_gradient_penalty(D, real, fake, opt.lambda_grad, 'cpu')
+                (errD_real + errD_fake + gp).backward()
+                gradsD = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in D.named_parameters()}
+                optimizerD.step()
+            errG = -D(fake).mean() * opt.disc_loss_weight
+            generated = netG(Z_init, noise_amps, mode="rec")
+            rec_loss = opt.alpha * rec_loss_fn(generated, real)
+            netG.zero_grad()
+            (errG + rec_loss).backward()
+            gradsG = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in netG.named_parameters()}
+            for _ in range(opt.Gsteps):
+                optimizerG.step()
+        fx['iters'].append({'noise_init': rec.normals[0], 'noises': rec.normals[1:], 'alphas': list(rec.rands),
+                            'errD_real': errD_real.detach().clone(), 'errD_fake': errD_fake.detach().clone(),
+                            'gradient_penalty': gp.detach().clone(), 'errG': errG.detach().clone(), 'rec_loss': rec_loss.detach().clone(),
+                            'fake': fake.detach().clone(), 'generated': generated.detach().clone(), 'gradsD': gradsD, 'gradsG': gradsG,
+                            'noise_amps': list(noise_amps), 'G_after': sd_clone(netG), 'D_after': sd_clone(D)})
+    return fx
+
+
 def op_fixtures(images, n3, n2, losses, mutils):
     """Per-op fixtures on odd shapes (halo bugs), produced by the reference's own block classes."""
     gen = torch.Generator().manual_seed(7)
@@ -319,6 +391,8 @@ def main():
     torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 3, 1, seed=102), os.path.join(OUT, 'step3d_gan_s3.pt'))
     torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=1), 2, 2, 2, seed=103), os.path.join(OUT, 'step2d_gan_s2.pt'))
     torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=104), os.path.join(OUT, 'step2d_vae_s1.pt'))
+    torch.save(run_baseline_steps(images, n3, mutils, make_opt(Dsteps=2, Gsteps=1, alpha=10.0, train_depth=1), 2, 1, seed=105),
+               os.path.join(OUT, 'baseline3d_s2.pt'))
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -53,3 +53,49 @@ def test_train_step_matches_reference(fname):
 def test_smoke_entry():
     from smoke_step import run_smoke
     run_smoke()
+
+
+def test_baseline_singan_step_matches_reference():
+    """BASELINE config 5: GeneratorSG + BaselineStageTrainer (HIP) against the reference-generated fixture."""
+    from helpers import NoiseFeed, hip_opt
+    from hp_vae_gan_amd import train as hp_train
+    from hp_vae_gan_amd.modules import networks_3d
+    fx = load_golden("baseline3d_s2.pt")
+    s = fx["scale_idx"]
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], 3, s, dev)
+    netG = networks_3d.GeneratorSG(opt)
+    for _ in range(s):
+        netG.init_next_stage()
+    assert list(netG.state_dict().keys()) == list(fx["G_init"].keys())
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    netD = networks_3d.WDiscriminator3D(opt)
+    netD.load_state_dict(fx["D_init"])
+    netD.to(dev)
+    opt.Noise_Amps = list(fx["noise_amps_init"])
+    opt.Z_init = fx["Z_init"].to(dev)
+    opt.record_grads = True
+    tr = hp_train.BaselineStageTrainer(opt, netG, netD)
+    rec = fx["iters"][0]
+    netG.noise_source = NoiseFeed(rec["noises"], dev)
+    out = tr.step(fx["real"].to(dev), noise_init=rec["noise_init"].to(dev), alphas=rec["alphas"])
+    assert opt.Noise_Amps == pytest.approx(rec["noise_amps"], rel=1e-4)
+    for k in ("errD_real", "errD_fake", "gradient_penalty"):
+        assert_close(out[k], rec[k], 3e-3, "baseline." + k)  # after the first of two D updates: post-optimizer tolerance
+    assert_close(out["errG"], rec["errG"], 3e-3, "baseline.errG")
+    assert_close(out["rec_loss"], rec["rec_loss"], RTOL, "baseline.rec_loss")
+    assert_close(out["generated"], rec["generated"], RTOL, "baseline.generated")
+    assert_close(out["fake"], rec["fake"], RTOL, "baseline.fake")
+    gotG = flat_to_named(out["gradG_flat"], tr.arenaG, netG)
+    for k, g in rec["gradsG"].items():
+        if g is None:
+            assert float(gotG[k].abs().max()) == 0.0, k
+        else:
+            assert_close(gotG[k], g, 3e-3, "baseline.gradG." + k, atol=bn_bias_atol(k, rec["gradsG"], 1e-7))
+    lr = fx["opt"]["lr_g"]
+    sdG, sdD = netG.state_dict(), netD.state_dict()
+    for k, v in rec["G_after"].items():
+        assert_close(sdG[k].float(), v.float(), RTOL, "baseline.G_after." + k, atol=2 * lr)
+    for k, v in rec["D_after"].items():
+        assert_close(sdD[k].float(), v.float(), RTOL, "baseline.D_after." + k, atol=4 * lr)

@@ -197,3 +197,31 @@ def test_c_restatement_of_conv_matches():
         lib.hpvg_oracle_conv_direct(x.contiguous().data_ptr() and ctypes.cast(x.data_ptr(), fp), ctypes.cast(w.data_ptr(), fp),
                                     ctypes.cast(b.data_ptr(), fp), ctypes.cast(y.data_ptr(), fp), shape[0], Cin, Cout, T, H, W, KT)
         assert_close(y, want, 1e-5, "conv_direct.c")
+
+
+def test_baseline_singan_step():
+    """SinGAN-3D baseline (BASELINE config 5): oracle step vs the reference-generated fixture."""
+    fx = load_golden("baseline3d_s2.pt")
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    s = fx["scale_idx"]
+    PG, PD = oracle_state(fx["G_init"]), oracle_state(fx["D_init"])
+    rec = fx["iters"][0]
+    amps = list(fx["noise_amps_init"])
+    amps.append(0)
+    z = O.generator_sg_forward(PG, opt, fx["Z_init"], amps, "rec", None)
+    amps[-1] = opt.noise_amp_init * float(torch.sqrt(O.mse(fx["real"], z))) / opt.batch_size
+    assert amps == pytest.approx(rec["noise_amps"], rel=1e-5)
+    out = O.baseline_train_step(PG, PD, opt, s, fx["real"], fx["Z_init"], rec["noise_init"], iter(rec["noises"]),
+                                [a.reshape(()) for a in rec["alphas"]], amps, {}, {})
+    for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
+        assert_close(out[k], rec[k], 1e-4, "baseline." + k)
+    for k, g in rec["gradsG"].items():
+        if g is not None:
+            assert_close(out["gradsG"][k], g, 2e-4, "baseline.gradG." + k, atol=bn_bias_atol(k, rec["gradsG"]))
+    lr = opt.lr_g
+    for k, v in rec["G_after"].items():
+        assert_close(PG[k].float(), v.float(), 1e-4, "baseline.G_after." + k, atol=2 * lr)
+    for k, v in rec["D_after"].items():
+        assert_close(PD[k].float(), v.float(), 1e-4, "baseline.D_after." + k, atol=4 * lr)
