@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--stages", type=str, default="0-9", help="pyramid stages in a step, e.g. 0-9 or 9")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stages", type=str, default="0-5")
+    ap.add_argument("--graph-stages", type=str, default="none",
+                    help="stages whose iteration is replayed as a hipGraph, e.g. 0-5 (measured: no gain - the small stages "
+                         "are bound by the serial chain of ~10 us kernels on the GPU, not by host launches); default none")
     ap.add_argument("--config", choices=["video", "image"], default="video",
                     help="video = BASELINE configs[2] (the metric's config, default); image = configs[1] (2-D path)")
     args = ap.parse_args()
@@ -243,6 +246,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # hipGraph replay for the launch-bound small stages (single-GPU path): one eager iteration (noise-amplitude
+    # calibration, workspace sizing), then capture.  The stage holding the roofline kernel stays eager so that the
+    # kernel's launches can be bracketed by events.
+    graph_stages = [] if args.graph_stages == "none" else parse(args.graph_stages)
+    if world == 1:
+        for s, trainer, real, real_zero in built:
+            if s in graph_stages and s != max(stages):
+                trainer.step(real, real_zero)
+                trainer.enable_graph(real, real_zero)
     # Stage-major order, as training proceeds (train_video.py:414-417: each stage runs its iterations before the next
     # stage starts): W warm-up then K timed iterations of every stage = K "steps" of one iteration per stage.
     for i in range(runner.n):
@@ -313,7 +325,8 @@ def main():
                                     if CONFIG == "video" else
                                     "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path); ") +
                                    "step = 1 train iteration at each pyramid stage %s" % args.stages,
-                       "stages": stages, "parallelism": "single GPU" if world == 1 else "rec/rand generator passes on ranks 0/1 + discriminator work split over the batch (2 working ranks of %d)" % world},
+                       "stages": stages, "hipgraph_stages": [s for s in graph_stages if s in stages and s != max(stages)] if world == 1 else [],
+                       "parallelism": "single GPU" if world == 1 else "rec/rand generator passes on ranks 0/1 + discriminator work split over the batch (2 working ranks of %d)" % world},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -500,10 +500,14 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
   if (coef_out && blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = coef; coef_out[1] = total; }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] *= coef;
 }
-// torch.optim.Adam (amsgrad=False, weight_decay=0)
+// torch.optim.Adam (amsgrad=False, weight_decay=0).  The step count comes either from the host (`step`) or, when
+// step_dev != nullptr, from device memory (hipGraph replays: the captured launch must not bake the count in).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
-                                                    float bc1, float bc2_sqrt) {
+                                                    int step, const int* __restrict__ step_dev) {
+  const int t = step_dev ? step_dev[0] : step;
+  const float bc1 = 1.f - powf(beta1, (float)t);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)t));
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i];
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] = p[i] - step_size * (mi / denom);
   }
 }
+__global__ void counter_inc_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
 
 inline int ew_blocks(long n) {
   long nb = (n + 256 * 4 - 1) / (256 * 4);
@@ -728,14 +733,18 @@ int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, fl
   hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqsum, max_norm, coef_out);
   return hpvg_launch_status();
 }
-// one Adam step over a flat range; step >= 1 is the 1-based step count
+// one Adam step over a flat range; step >= 1 is the 1-based step count, or (step_dev != NULL) read from device memory
 int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                       int step, void* stream) {
-  if (!p || !g || !m || !v || n < 1 || step < 1) return HPVG_ERR_ARG;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+                       int step, const int* step_dev, void* stream) {
+  if (!p || !g || !m || !v || n < 1 || (!step_dev && step < 1)) return HPVG_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2));
+                     step, step_dev);
+  return hpvg_launch_status();
+}
+// counter[0] += 1 (device-resident optimizer step count)
+int hpvg_counter_inc_i32(int* counter, void* stream) {
+  if (!counter) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
   return hpvg_launch_status();
 }
 

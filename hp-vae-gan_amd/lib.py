@@ -63,7 +63,8 @@ _SIGS = {
     "hpvg_div_scalar_f32": [P, P, P, L, P],
     "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, I, P],
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],
-    "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P],
+    "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
+    "hpvg_counter_inc_i32": [P, P],
 }
 _SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
 
@@ -116,7 +117,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise RuntimeError("hp-vae-gan_amd: tensor is on %s; these ops run only on an MI355X device (no CPU fallback)" % t.device)
-    if t.dtype != torch.float32 and t.dtype != torch.float64 and t.dtype != torch.uint8:
+    if t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int32):
         raise RuntimeError("hp-vae-gan_amd: unsupported dtype %s" % t.dtype)
     if not t.is_contiguous():
         raise RuntimeError("hp-vae-gan_amd: tensor must be contiguous")

@@ -560,6 +560,10 @@ def clip_scale_(flat_grad, sq, max_norm, coef_out=None):
          stream())
 
 
-def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, step_dev=None):
     call("hpvg_adam_step_f32", ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_long(p.numel()), float(lr), float(beta1), float(beta2),
-         float(eps), int(step), stream())
+         float(eps), int(step), ptr(step_dev), stream())
+
+
+def counter_inc_(counter):
+    call("hpvg_counter_inc_i32", ptr(counter), stream())

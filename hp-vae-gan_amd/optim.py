@@ -79,13 +79,16 @@ class FlatAdam:
                                 "m": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device),
                                 "v": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device)})
         self.t = 0
+        # device-resident copy of the step count: a hipGraph replay of step() must not bake the count into the launch
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=arena.flat.device)
 
     def step(self):
         self.t += 1
+        ops.counter_inc_(self.t_dev)
         for g in self.groups:
             lo, hi = g["lo"], g["hi"]
             ops.adam_step_(self.arena.flat[lo:hi], self.arena.grad[lo:hi], g["m"], g["v"], g["lr"], self.betas[0], self.betas[1],
-                           self.eps, self.t)
+                           self.eps, self.t, self.t_dev)
 
     def state_dict(self):
         return {"t": self.t, "groups": [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in g.items()} for g in self.groups]}

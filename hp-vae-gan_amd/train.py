@@ -87,10 +87,47 @@ class StageTrainer:
                 opt.noise_amp = opt.noise_amp_init * rmse.item() / opt.batch_size
                 opt.Noise_Amps[-1] = opt.noise_amp
 
+    # ---- hipGraph execution of the iteration (launch-bound small stages: ~350-900 launches per iteration)
+    def enable_graph(self, real, real_zero):
+        """Capture one iteration into a hipGraph and replay it from then on (call after >= 1 eager iteration, i.e.
+        after the noise-amplitude calibration and once every workspace has its final size).  Inside the graph the GP
+        alpha is drawn from the DEVICE generator (a fresh host->device copy cannot be replayed); Adam reads its step
+        count from device memory.  Inputs are copied into static buffers before each replay."""
+        if self.iteration < 1:
+            raise RuntimeError("run one eager iteration first (noise-amplitude calibration is not capturable)")
+        self._g_real = real.clone()
+        self._g_rz = self._g_real if real_zero is real else real_zero.clone()
+        self._graph_alpha = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._step_eager(self._g_real, self._g_rz)  # warm-up on the capture stream's side (allocator, workspaces)
+        torch.cuda.current_stream().wait_stream(side)
+        it = self.iteration
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_out = self._step_eager(self._g_real, self._g_rz)
+        self.iteration = it  # capture records the launches, it does not execute the iteration
+        return self
+
     def step(self, real, real_zero, noise_init=None, alpha=None):
         """One training iteration.  `noise_init` / `alpha` may be injected (parity tests); otherwise drawn like the
         reference does (utils.generate_noise on the device; torch.rand(1,1) on the CPU generator)."""
+        if getattr(self, '_graph', None) is not None and noise_init is None and alpha is None:
+            if real.data_ptr() != self._g_real.data_ptr():
+                self._g_real.copy_(real)
+            if real_zero.data_ptr() != self._g_rz.data_ptr() and self._g_rz is not self._g_real:
+                self._g_rz.copy_(real_zero)
+            self._graph.replay()
+            self.iteration += 1
+            self.last = self._g_out
+            return self._g_out
+        return self._step_eager(real, real_zero, noise_init, alpha)
+
+    def _step_eager(self, real, real_zero, noise_init=None, alpha=None):
         opt, netG = self.opt, self.netG
+        if alpha is None and getattr(self, '_graph_alpha', False):
+            alpha = torch.rand(1, device=real.device)
         if noise_init is None:
             noise_init = utils.generate_noise(size=opt.Z_init_size, device=opt.device)
         if self.iteration == 0:

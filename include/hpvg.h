@@ -107,8 +107,10 @@ int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, cons
 /* ---- optimizer: clip_grad_norm_ (train_video.py:201) and optim.Adam (train_video.py:55,88) over flat arenas */
 int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, float* coef_out /*nullable, 2 floats*/,
                         void* stream);
+/* step: 1-based count from the host, or step_dev (device int, non-NULL) for hipGraph replays */
 int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                       int step, void* stream);
+                       int step, const int* step_dev, void* stream);
+int hpvg_counter_inc_i32(int* counter, void* stream);
 
 #ifdef __cplusplus
 }

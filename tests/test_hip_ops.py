@@ -227,9 +227,12 @@ def test_adam_and_clip(ops):
     assert_close(info.cpu(), torch.stack([coef, total]), RTOL, "clip.info")
     pd, md, vd = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     po, state = p.clone(), {}
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
     for t in range(1, 4):
         O.adam_step(po, g_ * t, state, 5e-4, 0.5)
-        ops.adam_step_(pd, (gd * t).contiguous(), md, vd, 5e-4, 0.5, 0.999, 1e-8, t)
+        ops.counter_inc_(cnt)
+        # steps 1-2 take the count from the host argument, step 3 from device memory (the hipGraph-safe path)
+        ops.adam_step_(pd, (gd * t).contiguous(), md, vd, 5e-4, 0.5, 0.999, 1e-8, t if t < 3 else 999, None if t < 3 else cnt)
     assert_close(pd, po, 1e-5, "adam.p")
     assert_close(md, state["m"], RTOL, "adam.m")
     assert_close(vd, state["v"], RTOL, "adam.v")
