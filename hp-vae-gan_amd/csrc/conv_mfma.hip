@@ -40,6 +40,10 @@ struct ConvFwdArgs {
   int B, Cin, Cout, T, H, W;
   int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, ntiles, mbtot, nj, S;
   int in_lrelu, out_lrelu;
+  // split-K (latency-bound grids): blockIdx.z owns channel chunks [z*cps, (z+1)*cps) and writes raw partial sums
+  float* part;       // nullptr = no split
+  long part_stride;  // floats per split slab (= B*Cout*T*H*W)
+  int cps;
 };
 
 template <int CP> struct AVecT;
@@ -104,8 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
 
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  for (int ch = 0; ch < a.nchunk; ++ch) {
-    if (ch > 0) __syncthreads();
+  const int ch_lo = a.part ? (int)blockIdx.z * a.cps : 0;
+  const int ch_hi = a.part ? (ch_lo + a.cps < a.nchunk ? ch_lo + a.cps : a.nchunk) : a.nchunk;
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
+    if (ch > ch_lo) __syncthreads();
     if (!prologue) {
       // ---------------- stage CC x KT planes by LDS-DMA: no VGPR round trip, every load of the chunk in flight at
       // once; out-of-image lanes read a global zero word, lanes past the plane end are masked off
@@ -235,9 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       for (int e = 0; e < 16; ++e) {
         const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (co < a.Cout) {
-          float val = acc[m][i][e] + bias_r[m][e];
-          if (a.out_lrelu) val = hpvg_lrelu(val);
-          a.y[((long)b * a.Cout + co) * a.T * HW + sp] = val;
+          const long oi = ((long)b * a.Cout + co) * a.T * HW + sp;
+          if (a.part) {
+            a.part[(long)blockIdx.z * a.part_stride + oi] = acc[m][i][e];  // raw partial; bias/activation in the reduce
+          } else {
+            float val = acc[m][i][e] + bias_r[m][e];
+            if (a.out_lrelu) val = hpvg_lrelu(val);
+            a.y[oi] = val;
+          }
         }
       }
     }
@@ -456,6 +467,19 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   wp[idx] = val;
 }
 
+// y = act(bias[c] + sum_z part[z]) : finishing pass of the split-K launch (fixed summation order: reproducible)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, int nsplit, long slab, int C, long S,
+                                                                  int lrelu) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slab; i += (long)gridDim.x * 256) {
+    float v = part[i];
+    for (int z = 1; z < nsplit; ++z) v += part[(long)z * slab + i];
+    if (bias) v += bias[(i / S) % C];
+    if (lrelu) v = hpvg_lrelu(v);
+    y[i] = v;
+  }
+}
+
 inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
 
 struct Plan {
@@ -539,6 +563,19 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipel
   return p;
 }
 
+// Split-K decision for latency-bound grids: when the classic grid has fewer workgroups than the chip has slots, the
+// channel chunks of every tile are spread over blockIdx.z (each workgroup then runs a 1/nsplit-long serial chain) and
+// a finishing kernel sums the slabs.  Returns the number of splits (1 = no split).
+inline int conv_nsplit(const Plan& pc, int B, int T, int nchunk) {
+  const long nwg = (long)B * T * pc.nth * pc.ntw * pc.gridy;
+  if (nchunk < 2 || nwg >= 2L * HPVG_NUM_CU) return 1;
+  long want = (3L * HPVG_NUM_CU + nwg - 1) / nwg;  // aim at ~3 workgroups per CU
+  if (want > nchunk) want = nchunk;
+  if (want < 2) return 1;
+  const int cps = hpvg_cdiv(nchunk, (int)want);
+  return hpvg_cdiv(nchunk, cps);
+}
+
 template <int CC, int KT, int MB, int NB>
 int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
   static bool attr_set = false, attr_set2 = false;
@@ -560,7 +597,7 @@ int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
       (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles, p.gridy), dim3(256), p.lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles, p.gridy, a.part ? hpvg_cdiv(a.nchunk, a.cps) : 1), dim3(256), p.lds, s, a);
   return hpvg_launch_status();
 }
 
@@ -614,23 +651,26 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 // f = identity, or (in_scale[c]*x + in_shift[c]) followed by LeakyReLU(0.2) when in_lrelu (zero padding
 // is applied AFTER f, as in the reference where f is the previous block's BatchNorm+LeakyReLU output).
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
-                      int in_lrelu, float* y, int out_lrelu, int B, int Cin, int Cout, int T, int H, int W, int KT,
-                      void* stream) {
+                      int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
+                      int W, int KT, void* stream) {
   if (!x || !wp || !y) return HPVG_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
-  // development knob: HPVG_CONV_PIPE=0/1 forces the kernel variant (default: auto)
+  // development knob: HPVG_CONV_PIPE = 0 classic (no split) / 1 pipelined persistent / 3 classic + split-K; default auto
   static const int force = [] { const char* e = getenv("HPVG_CONV_PIPE"); return e ? atoi(e) : -1; }();
-  // Variant choice (measured, tools/perf_conv.py): when the classic grid fits on the chip in one wave of workgroups
-  // (<= 512) the launch is latency bound and the software-pipelined persistent kernel wins (stage 0: 135 -> 92 us);
-  // for larger grids two co-resident workgroups per CU hide each other's staging better than one wave per SIMD can.
+  // Variant choice (measured, tools/perf_conv.py).  Chip-filling grids: classic kernel, two co-resident workgroups per
+  // CU hide each other's staging.  Latency-bound grids (< 512 workgroups): split the channel chunks over blockIdx.z
+  // (split-K) when the caller provided workspace, else the software-pipelined persistent kernel.
+  const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
+  const int nchunk_c = hpvg_cdiv(Cin, conv_cc(Cin));
+  int nsplit = conv_nsplit(pc, B, T, nchunk_c);
+  const size_t slab = (size_t)B * Cout * T * H * W;
+  if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * slab * sizeof(float))) nsplit = 1;
+  if (force == 0 || force == 1) nsplit = 1;
   bool pipelined = false;
-  if (in_scale == nullptr) {
-    const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
-    pipelined = (long)B * T * pc.nth * pc.ntw * pc.gridy <= 2L * HPVG_NUM_CU;
-  }
-  if (force == 0) pipelined = false;
+  if (nsplit == 1 && in_scale == nullptr) pipelined = (long)B * T * pc.nth * pc.ntw * pc.gridy <= 2L * HPVG_NUM_CU;
+  if (force == 0 || force == 3) pipelined = false;
   if (force == 1 && in_scale == nullptr) pipelined = true;
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, pipelined);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
@@ -649,9 +689,27 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
     a.S = (int)(a.ntiles < S ? a.ntiles : S);
   }
   a.in_lrelu = in_lrelu; a.out_lrelu = out_lrelu;
+  a.part = nsplit > 1 ? (float*)ws : nullptr;
+  a.part_stride = (long)slab;
+  a.cps = nsplit > 1 ? hpvg_cdiv(a.nchunk, nsplit) : a.nchunk;
   hipStream_t s = (hipStream_t)stream;
-  if (CC == 8) return KT == 3 ? dispatch_conv<8, 3>(a, p, s) : dispatch_conv<8, 1>(a, p, s);
-  return KT == 3 ? dispatch_conv<4, 3>(a, p, s) : dispatch_conv<4, 1>(a, p, s);
+  int rc;
+  if (CC == 8) rc = KT == 3 ? dispatch_conv<8, 3>(a, p, s) : dispatch_conv<8, 1>(a, p, s);
+  else rc = KT == 3 ? dispatch_conv<4, 3>(a, p, s) : dispatch_conv<4, 1>(a, p, s);
+  if (rc != HPVG_OK || nsplit == 1) return rc;
+  long nb = (long)((slab + 1023) / 1024);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)ws, bias, y,
+                     hpvg_cdiv(a.nchunk, a.cps), (long)slab, Cout, (long)T * H * W, out_lrelu);
+  return hpvg_launch_status();
+}
+
+// workspace the split-K path of hpvg_conv_fwd_f32 wants for this shape (0: the shape never splits)
+size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
+  const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
+  const int nsplit = conv_nsplit(pc, B, T, hpvg_cdiv(Cin, conv_cc(Cin)));
+  return nsplit > 1 ? (size_t)nsplit * B * Cout * T * H * W * sizeof(float) : 0;
 }
 
 // Debug/introspection: the tile plan the launcher will use (for tests and DESIGN.md tables).

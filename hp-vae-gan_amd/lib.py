@@ -29,7 +29,8 @@ Z = ctypes.c_size_t
 _SIGS = {
     "hpvg_conv_wpack_floats": [I, I, I],
     "hpvg_conv_pack_weight_f32": [P, P, P, I, I, I, I, P],
-    "hpvg_conv_fwd_f32": [P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P],
+    "hpvg_conv_fwd_ws_bytes": [I, I, I, I, I, I, I],
+    "hpvg_conv_fwd_f32": [P, P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_fwd_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
@@ -66,7 +67,7 @@ _SIGS = {
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
     "hpvg_counter_inc_i32": [P, P],
 }
-_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
 
 
 def header_symbols():

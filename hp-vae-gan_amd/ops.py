@@ -110,8 +110,11 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     if _kernel_timer is not None and _kernel_timer.match({"Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip}):
         timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         timed[0].record()
+    nws = call("hpvg_conv_fwd_ws_bytes", B, cin_k, cout_k, T, H, W, KT)
+    ws = workspace(nws, x.device) if nws else None
     call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
-         1 if out_lrelu else 0, B, cin_k, cout_k, T, H, W, KT, stream())
+         1 if out_lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT,
+         stream())
     if timed is not None:
         timed[1].record()
         _kernel_timer.events.append(((B, cin_k, T, H, W), timed[0], timed[1]))

@@ -36,9 +36,12 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 /* y = conv(f(x), wp) + bias; f = identity or LeakyReLU_opt(in_scale[c]*x + in_shift[c]) applied before zero padding
  * (fused BatchNorm-apply of the producing ConvBlock3D, networks_3d.py:54-55); out_lrelu: LeakyReLU(0.2) epilogue
  * (ConvBlock3DSN, networks_3d.py:59-70). bias may be NULL. */
+/* ws (optional, may be NULL): scratch for the split-K path taken by latency-bound shapes; size from
+ * hpvg_conv_fwd_ws_bytes (0 = this shape never splits).  Without it those shapes run unsplit (slower, same result). */
+size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT);
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
-                      int in_lrelu, float* y, int out_lrelu, int B, int Cin, int Cout, int T, int H, int W, int KT,
-                      void* stream);
+                      int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
+                      int W, int KT, void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
 /* dW (natural layout) of the conv above: aten::convolution_backward weight half, reached from
  * total_loss.backward() / errD_total.backward() (train_video.py:182,200). accumulate!=0: dw += result. */
