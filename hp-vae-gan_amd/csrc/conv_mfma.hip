@@ -566,10 +566,13 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipel
 // Split-K decision for latency-bound grids: when the classic grid has fewer workgroups than the chip has slots, the
 // channel chunks of every tile are spread over blockIdx.z (each workgroup then runs a 1/nsplit-long serial chain) and
 // a finishing kernel sums the slabs.  Returns the number of splits (1 = no split).
-inline int conv_nsplit(const Plan& pc, int B, int T, int nchunk) {
+inline int conv_nsplit(const Plan& pc, int B, int T, int nchunk, int KT) {
   const long nwg = (long)B * T * pc.nth * pc.ntw * pc.gridy;
-  if (nchunk < 2 || nwg >= 2L * HPVG_NUM_CU) return 1;
+  // measured (bench.py per-stage it/s): pays for 3x3x3 convs on grids of ~100-500 workgroups; loses for 2-D convs
+  // (9 taps per chunk: the partial-slab write + finishing kernel outweigh the shorter chain) and for tiny grids
+  if (KT != 3 || nchunk < 2 || nwg >= 2L * HPVG_NUM_CU || nwg < 128) return 1;
   long want = (3L * HPVG_NUM_CU + nwg - 1) / nwg;  // aim at ~3 workgroups per CU
+  if (want > 4) want = 4;
   if (want > nchunk) want = nchunk;
   if (want < 2) return 1;
   const int cps = hpvg_cdiv(nchunk, (int)want);
@@ -664,7 +667,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   // (split-K) when the caller provided workspace, else the software-pipelined persistent kernel.
   const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
   const int nchunk_c = hpvg_cdiv(Cin, conv_cc(Cin));
-  int nsplit = conv_nsplit(pc, B, T, nchunk_c);
+  int nsplit = conv_nsplit(pc, B, T, nchunk_c, KT);
   const size_t slab = (size_t)B * Cout * T * H * W;
   if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * slab * sizeof(float))) nsplit = 1;
   if (force == 0 || force == 1) nsplit = 1;
@@ -708,7 +711,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
   const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
-  const int nsplit = conv_nsplit(pc, B, T, hpvg_cdiv(Cin, conv_cc(Cin)));
+  const int nsplit = conv_nsplit(pc, B, T, hpvg_cdiv(Cin, conv_cc(Cin)), KT);
   return nsplit > 1 ? (size_t)nsplit * B * Cout * T * H * W * sizeof(float) : 0;
 }
 
