@@ -16,8 +16,8 @@
 //   K = (tap, input-channel) - two input channels per v_mfma_f32_32x32x2_f32.
 //
 // Data movement: the input tile (CC channels x KT time planes x (Th+2) x (Tw+2), zero padded) is
-// staged through LDS one channel chunk at a time (register staged, so the producer's
-// BatchNorm-apply + LeakyReLU can be fused into the load); the B operand is read with
+// staged through LDS one channel chunk at a time (LDS-DMA; register staged when the producer's
+// BatchNorm-apply + LeakyReLU is fused into the load); the B operand is read with
 // conflict-free ds_read_b32 (32 consecutive dwords per half wave).  The A operand (weights) is
 // pre-packed in fragment order and read straight from L2 with one 16-byte load per lane per
 // (tap, m-tile); all workgroups read the same 442 KB so it stays L2 resident.
@@ -30,6 +30,30 @@ namespace {
 // source of zero padding for the LDS-DMA staging (out-of-image lanes read this word)
 __device__ const float g_zero_word[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+#ifdef HPVG_TRACE
+// development build only (tools/trace_conv.py): per-workgroup start/end (100 MHz clock) and placement
+__device__ unsigned long long g_trace[8192 * 4];
+__device__ unsigned long long g_phase[8192 * 4];  // per workgroup (wave 0): cycles issuing DMA, waiting for it, in the MFMA loop, epilogue
+#define HPVG_PH(i) { unsigned long long now_ = __builtin_readcyclecounter(); ph_a[i] += now_ - ph_t; ph_t = now_; }
+#define HPVG_PH_INIT unsigned long long ph_t = __builtin_readcyclecounter(); unsigned long long ph_a[4] = {0, 0, 0, 0};
+#define HPVG_PH_END if (threadIdx.x == 0) { for (int i_ = 0; i_ < 4; ++i_) g_phase[4 * blockIdx.x + i_] = ph_a[i_]; }
+#define HPVG_TRACE_BEGIN unsigned long long tr_t0 = wall_clock64(); unsigned long long tr_c0 = __builtin_readcyclecounter();
+#define HPVG_TRACE_END                                                              \
+  if (threadIdx.x == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 8192) { \
+    unsigned long long* tr = g_trace + 4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+    tr[0] = tr_t0;                                                                  \
+    tr[1] = wall_clock64();                                                         \
+    tr[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                              \
+    tr[3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) | ((__builtin_readcyclecounter() - tr_c0) << 8); \
+  }
+#else
+#define HPVG_TRACE_BEGIN
+#define HPVG_TRACE_END
+#define HPVG_PH(i)
+#define HPVG_PH_INIT
+#define HPVG_PH_END
+#endif
+
 struct ConvFwdArgs {
   const float* x;
   const float* wp;
@@ -38,12 +62,12 @@ struct ConvFwdArgs {
   const float* in_shift;
   float* y;
   int B, Cin, Cout, T, H, W;
-  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, ntiles, mbtot, nj, S;
+  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, mbtot, nj;
   int in_lrelu, out_lrelu;
-  // split-K (latency-bound grids): blockIdx.z owns channel chunks [z*cps, (z+1)*cps) and writes raw partial sums
-  float* part;       // nullptr = no split
-  long part_stride;  // floats per split slab (= B*Cout*T*H*W)
-  int cps;
+  // schedule: tiles [0, ndp*S) are data-parallel rounds (round k: tile k*S + g), tiles [skbase, ntl) are cut into
+  // (tile, channel-chunk) items dealt evenly over the S workgroups (stream-K)
+  int gridy, ntl, ndp, skbase;
+  float* skpart;  // [S][2][MB*NB*16][256] raw accumulator slabs of partially computed tiles
 };
 
 template <int CP> struct AVecT;
@@ -52,313 +76,170 @@ template <> struct AVecT<2> { typedef f32x2 type; };
 
 constexpr int NJMAX = 4;  // (Th+2)*RS <= 1024
 
+// ------------------------------------------------------------------------------------------
+// Schedule (stream-K).  A workgroup's serial K loop over one tile (8 chunks x 864 MFMAs per wave) lasts ~200 us, so a
+// grid of one workgroup per tile with 1-5 tiles per CU slot is badly quantised (2080 tiles on 512 slots: the fifth
+// round is 6 % full; 560 tiles: the second round 9 %).  The grid is therefore exactly the number of co-resident
+// workgroups S (2 per CU, 512).  Tiles [0, ndp*S) are handed out whole (round k: tile k*S + g); the remaining tiles
+// are cut into (tile, channel chunk) items and the item list is split evenly over the S workgroups, so every
+// workgroup runs the same number of chunk iterations +-1.  A tile whose chunks end up in more than one workgroup is
+// written as raw accumulator slabs (register order, fully coalesced) and finished by conv_fixup_kernel in workgroup
+// order (reproducible; no float atomics).  With S = number of tiles the same kernel is the plain one-workgroup-per-tile
+// launch (no workspace needed).
+// Measured on MI355X (tools/trace_conv.py, per-workgroup timeline): one workgroup per CU already saturates the matrix
+// pipe (2 per CU: +3 %); the sustained shader clock under this load is 2.03-2.07 GHz with real data (2.29 GHz when the
+// operands are zeros), i.e. the fp32 MFMA ceiling of the part is ~134 TFLOP/s, not the 157.3 of 2.4 GHz.
+struct SkTile { int b, t, h0, w0, mb0; };
+__device__ __forceinline__ SkTile sk_decode_tile(const ConvFwdArgs& a, int tile, int MB) {
+  SkTile c;
+  const int yb = tile % a.gridy;
+  int r = tile / a.gridy;
+  const int tw_i = r % a.ntw; r /= a.ntw;
+  const int th_i = r % a.nth; r /= a.nth;
+  c.t = r % a.T;
+  c.b = r / a.T;
+  c.h0 = th_i * a.Th;
+  c.w0 = tw_i * a.Tw;
+  c.mb0 = yb * MB;
+  return c;
+}
+
 template <int CC, int KT, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) {
   constexpr int CP = CC / 2;
   constexpr int TAPS = KT * 9;
   typedef typename AVecT<CP>::type AVec;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) float xs[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-
-  const int tile = hpvg_xcd_remap(blockIdx.x, a.ntiles);
-  const int tw_i = tile % a.ntw;
-  int r = tile / a.ntw;
-  const int th_i = r % a.nth;
-  r /= a.nth;
-  const int t = r % a.T;
-  const int b = r / a.T;
-  const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
-  const int mb0 = blockIdx.y * MB;
   const long HW = (long)a.H * a.W;
   const int RS = a.RS, PL = a.PL;
-
-  // ---- per-thread staging slots: position p = j*256+tid inside one (Th+2) x RS input plane
-  int gofs[NJMAX];
-  unsigned okmask = 0, wmask = 0;
   const int plload = (a.Th + 2) * RS;
-#pragma unroll
-  for (int j = 0; j < NJMAX; ++j) {
-    const int p = j * 256 + tid;
-    gofs[j] = 0;
-    if (j < a.nj && p < plload) {
-      const int hh = p / RS, ww = p - hh * RS;
-      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-      wmask |= 1u << j;
-      if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
-        okmask |= 1u << j;
-        gofs[j] = gh * a.W + gw;
-      }
-    }
-  }
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][i][e] = 0.f;
-
   const bool prologue = a.in_scale != nullptr;
   const float* xl = xs + half * KT * PL + l31 + wave * 32;
 
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const int ch_lo = a.part ? (int)blockIdx.z * a.cps : 0;
-  const int ch_hi = a.part ? (ch_lo + a.cps < a.nchunk ? ch_lo + a.cps : a.nchunk) : a.nchunk;
-  for (int ch = ch_lo; ch < ch_hi; ++ch) {
-    if (ch > ch_lo) __syncthreads();
-    if (!prologue) {
-      // ---------------- stage CC x KT planes by LDS-DMA: no VGPR round trip, every load of the chunk in flight at
-      // once; out-of-image lanes read a global zero word, lanes past the plane end are masked off
-#pragma unroll 1
-      for (int pl = 0; pl < CC * KT; ++pl) {
-        const int c = pl / KT, dt = pl - c * KT;
-        const int cg = ch * CC + c;
-        const int tt = t + dt - (KT == 3 ? 1 : 0);
-        const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
-        const float* src = a.x + (((long)b * a.Cin + (valid ? cg : 0)) * a.T + (valid ? tt : 0)) * HW;
-        float* dst = xs + pl * PL + wave * 64;
-#pragma unroll
-        for (int j = 0; j < NJMAX; ++j)
-          if ((wmask >> j) & 1u)
-            __builtin_amdgcn_global_load_lds((gptr_t)((valid && ((okmask >> j) & 1u)) ? src + gofs[j] : g_zero_word),
-                                             (lptr_t)(dst + j * 256), 4, 0, 0);
-      }
+  HPVG_TRACE_BEGIN
+  const int S = gridDim.x;
+  const int g = hpvg_xcd_remap(blockIdx.x, S);
+  const long Isk = (long)(a.ntl - a.skbase) * a.nchunk;
+  int it = (int)((long)g * Isk / S);
+  const int it_hi = (int)((long)(g + 1) * Isk / S);
+  const int first_sk_tile = a.skbase + it / a.nchunk;
+
+  HPVG_PH_INIT
+  bool first_stage = true;
+  for (int k = 0;; ++k) {
+    int tile, ch_lo, ch_hi;
+    if (k < a.ndp) {
+      tile = k * S + g;
+      ch_lo = 0;
+      ch_hi = a.nchunk;
     } else {
-    // ---------------- stage CC x KT planes into LDS through registers (fused affine + LeakyReLU of the producer)
-#pragma unroll 2
-    for (int c = 0; c < CC; ++c) {
-      const int cg = ch * CC + c;
-      const bool cok = cg < a.Cin;
-      float sc = 1.f, sh = 0.f;
-      if (cok) {
-        sc = a.in_scale[cg];
-        sh = a.in_shift[cg];
-      }
-      float v[KT][NJMAX];
-#pragma unroll
-      for (int dt = 0; dt < KT; ++dt) {
-        const int tt = t + dt - (KT == 3 ? 1 : 0);
-        const bool tok = cok && tt >= 0 && tt < a.T;
-        const float* src = a.x + (((long)b * a.Cin + (cok ? cg : 0)) * a.T + (tok ? tt : 0)) * HW;
-#pragma unroll
-        for (int j = 0; j < NJMAX; ++j) {
-          const bool ld = tok && ((okmask >> j) & 1u);
-          v[dt][j] = ld ? src[gofs[j]] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < KT; ++dt) {
-        const int tt = t + dt - (KT == 3 ? 1 : 0);
-        const bool tok = cok && tt >= 0 && tt < a.T;
-#pragma unroll
-        for (int j = 0; j < NJMAX; ++j) {
-          if ((wmask >> j) & 1u) {
-            float val = v[dt][j];
-            if (tok && ((okmask >> j) & 1u)) {
-              val = val * sc + sh;
-              if (a.in_lrelu) val = hpvg_lrelu(val);
-            }
-            xs[(c * KT + dt) * PL + j * 256 + tid] = val;
-          }
-        }
-      }
+      if (it >= it_hi) break;
+      const int tr = it / a.nchunk;
+      tile = a.skbase + tr;
+      ch_lo = it - tr * a.nchunk;
+      const int n = (a.nchunk - ch_lo < it_hi - it) ? a.nchunk - ch_lo : it_hi - it;
+      ch_hi = ch_lo + n;
+      it += n;
     }
-    }
-    __syncthreads();
+    const SkTile tc = sk_decode_tile(a, tile, MB);
+    const int b = tc.b, t = tc.t, h0 = tc.h0, w0 = tc.w0, mb0 = tc.mb0;
 
-    // ---------------- MFMA over (tap, channel pair)
-    const AVec* wpt = reinterpret_cast<const AVec*>(a.wp) + ((long)(ch * TAPS) * a.mbtot + mb0) * 64 + lane;
-    AVec av[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) av[m] = wpt[m * 64];
-    // B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (two register sets; CP is even, so the
-    // parity is static); past the chunk's last k-step this is a harmless in-buffer read.
-    float bv[2][NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) bv[0][i] = xl[i * 128];
-#pragma unroll 1
-    for (int dt = 0; dt < KT; ++dt) {
-#pragma unroll
-      for (int dh = 0; dh < 3; ++dh) {
-#pragma unroll
-        for (int dw = 0; dw < 3; ++dw) {
-          // prefetch the next tap's A fragments (the pack has tail padding)
-          wpt += (long)a.mbtot * 64;
-          AVec an[MB];
-#pragma unroll
-          for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
-          const float* xt = xl + dt * PL + dh * RS + dw;
-          const float* xn = (dw < 2) ? xt + 1 : (dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1 < KT ? dt + 1 : 0) * PL);
-#pragma unroll
-          for (int cp = 0; cp < CP; ++cp) {
-            const float* nx = (cp + 1 < CP) ? xt + (2 * (cp + 1) * KT) * PL : xn;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bv[(cp + 1) & 1][i] = nx[i * 128];
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this k-step's MFMAs
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-              for (int m = 0; m < MB; ++m)
-                acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[cp & 1][i], acc[m][i], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-          }
-#pragma unroll
-          for (int m = 0; m < MB; ++m) av[m] = an[m];
-        }
-      }
-    }
-  }
-
-  // ---------------- epilogue: bias, optional LeakyReLU, masked store
-  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float bias_r[MB][16];
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      bias_r[m][e] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int blk = wave + 4 * i;
-    const int q = blk * 32 + l31;
-    const int hh = q / RS, ww = q - hh * RS;
-    const int gh = h0 + hh, gw = w0 + ww;
-    const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
-    if (!ok) continue;
-    const long sp = (long)t * HW + (long)gh * a.W + gw;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (co < a.Cout) {
-          const long oi = ((long)b * a.Cout + co) * a.T * HW + sp;
-          if (a.part) {
-            a.part[(long)blockIdx.z * a.part_stride + oi] = acc[m][i][e];  // raw partial; bias/activation in the reduce
-          } else {
-            float val = acc[m][i][e] + bias_r[m][e];
-            if (a.out_lrelu) val = hpvg_lrelu(val);
-            a.y[oi] = val;
-          }
-        }
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Pipelined variant (no fused producer on the input): one persistent workgroup per CU (1 wave per SIMD), two LDS
-// buffers.  While the MFMA loop of work item i = (tile, channel chunk) runs out of buffer i&1, item i+1 is staged
-// into the other buffer by LDS-DMA (global_load_lds_dword, no VGPR round trip), one input plane per tap slotted
-// between the MFMAs so that staging rides in the matrix pipe's shadow.  One barrier per item.
-template <int CC, int KT, int MB, int NB>
-__global__ __launch_bounds__(256, 1) void conv_mfma_pipe_kernel(const ConvFwdArgs a) {
-  constexpr int CP = CC / 2;
-  constexpr int TAPS = KT * 9;
-  constexpr int NPL = CC * KT;  // input planes per chunk
-  typedef typename AVecT<CP>::type AVec;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int mb0 = blockIdx.y * MB;
-  const long HW = (long)a.H * a.W;
-  const int RS = a.RS, PL = a.PL;
-  const int BUF = NPL * PL;
-  const int plload = (a.Th + 2) * RS;
-  const int pt = (KT == 3 ? 1 : 0);
-
-  // staging state of the tile being loaded
-  int goff[NJMAX];
-  bool gok[NJMAX], gln[NJMAX];
-#pragma unroll
-  for (int j = 0; j < NJMAX; ++j) gln[j] = j < a.nj && j * 256 + tid < plload;
-  const float* sbase = a.x;  // x + b*Cin*T*HW of the staged tile
-  int st_t = 0;
-  auto setup = [&](int tile, int& b, int& t, int& h0, int& w0) {
-    const int tw_i = tile % a.ntw;
-    int r = tile / a.ntw;
-    const int th_i = r % a.nth;
-    r /= a.nth;
-    t = r % a.T;
-    b = r / a.T;
-    h0 = th_i * a.Th;
-    w0 = tw_i * a.Tw;
+    // ---- per-thread staging slots: position p = j*256+tid inside one (Th+2) x RS input plane
+    int gofs[NJMAX];
+    unsigned okmask = 0, wmask = 0;
 #pragma unroll
     for (int j = 0; j < NJMAX; ++j) {
       const int p = j * 256 + tid;
-      const int hh = p / RS, ww = p - hh * RS;
-      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-      gok[j] = gln[j] && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      goff[j] = gok[j] ? gh * a.W + gw : 0;
-    }
-    sbase = a.x + (long)b * a.Cin * a.T * HW;
-    st_t = t;
-  };
-  // stage input plane pl (= c*KT + dt) of channel chunk ch of the staged tile into buf
-  auto dma_plane = [&](int pl, int ch, float* buf) {
-    const int c = pl / KT, dt = pl - c * KT;
-    const int cg = ch * CC + c;
-    const int tt = st_t + dt - pt;
-    const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
-    const float* src = sbase + ((long)(valid ? cg : 0) * a.T + (valid ? tt : 0)) * HW;
-    float* dst = buf + pl * PL + wave * 64;
-#pragma unroll
-    for (int j = 0; j < NJMAX; ++j)
-      if (gln[j])
-        __builtin_amdgcn_global_load_lds((gptr_t)((valid && gok[j]) ? src + goff[j] : g_zero_word), (lptr_t)(dst + j * 256), 4, 0, 0);
-  };
-
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][i][e] = 0.f;
-
-  int tile = blockIdx.x;
-  if (tile >= a.ntiles) return;
-  int cb, ct, ch0, cw0;  // coordinates of the tile being computed (for its epilogue)
-  setup(tile, cb, ct, ch0, cw0);
-  for (int pl = 0; pl < NPL; ++pl) dma_plane(pl, 0, xs);
-  __syncthreads();
-
-  int cur = 0;
-  for (; tile < a.ntiles; tile += a.S) {
-    for (int ch = 0; ch < a.nchunk; ++ch) {
-      // ---- what to stage while computing (tile, ch)
-      const bool last_chunk = ch + 1 == a.nchunk;
-      int nch = ch + 1;
-      bool have_next = true;
-      int nb_, nt_, nh0_, nw0_;
-      if (last_chunk) {
-        nch = 0;
-        have_next = tile + a.S < a.ntiles;
-        if (have_next) setup(tile + a.S, nb_, nt_, nh0_, nw0_);
+      gofs[j] = 0;
+      if (j < a.nj && p < plload) {
+        const int hh = p / RS, ww = p - hh * RS;
+        const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+        wmask |= 1u << j;
+        if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+          okmask |= 1u << j;
+          gofs[j] = gh * a.W + gw;
+        }
       }
-      float* bufc = xs + cur * BUF;
-      float* bufn = xs + (cur ^ 1) * BUF;
-      int plnext = have_next ? 0 : NPL;
+    }
 
-      // ---- MFMA over (tap, channel pair) of the current chunk.  One wave per SIMD: nothing but this wave's own
-      // instruction order hides latency, so the B fragments of k-step s+1 are read from LDS before the MFMAs of
-      // k-step s (two register sets, static parity because CP is even) and the A fragments one tap ahead.
-      const float* xl = bufc + half * KT * PL + l31 + wave * 32;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][i][e] = 0.f;
+
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+      if (!first_stage) __syncthreads();  // every wave is done reading the previous chunk
+      first_stage = false;
+      HPVG_PH(3)
+      if (!prologue) {
+#pragma unroll 1
+        for (int pl = 0; pl < CC * KT; ++pl) {
+          const int c = pl / KT, dt = pl - c * KT;
+          const int cg = ch * CC + c;
+          const int tt = t + dt - (KT == 3 ? 1 : 0);
+          const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
+          const float* src = a.x + (((long)b * a.Cin + (valid ? cg : 0)) * a.T + (valid ? tt : 0)) * HW;
+          float* dst = xs + pl * PL + wave * 64;
+#pragma unroll
+          for (int j = 0; j < NJMAX; ++j)
+            if ((wmask >> j) & 1u)
+              __builtin_amdgcn_global_load_lds((gptr_t)((valid && ((okmask >> j) & 1u)) ? src + gofs[j] : g_zero_word),
+                                               (lptr_t)(dst + j * 256), 4, 0, 0);
+        }
+      } else {
+#pragma unroll 2
+        for (int c = 0; c < CC; ++c) {
+          const int cg = ch * CC + c;
+          const bool cok = cg < a.Cin;
+          float sc = 1.f, sh = 0.f;
+          if (cok) {
+            sc = a.in_scale[cg];
+            sh = a.in_shift[cg];
+          }
+          float v[KT][NJMAX];
+#pragma unroll
+          for (int dt = 0; dt < KT; ++dt) {
+            const int tt = t + dt - (KT == 3 ? 1 : 0);
+            const bool tok = cok && tt >= 0 && tt < a.T;
+            const float* src = a.x + (((long)b * a.Cin + (cok ? cg : 0)) * a.T + (tok ? tt : 0)) * HW;
+#pragma unroll
+            for (int j = 0; j < NJMAX; ++j) {
+              const bool ld = tok && ((okmask >> j) & 1u);
+              v[dt][j] = ld ? src[gofs[j]] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int dt = 0; dt < KT; ++dt) {
+            const int tt = t + dt - (KT == 3 ? 1 : 0);
+            const bool tok = cok && tt >= 0 && tt < a.T;
+#pragma unroll
+            for (int j = 0; j < NJMAX; ++j) {
+              if ((wmask >> j) & 1u) {
+                float val = v[dt][j];
+                if (tok && ((okmask >> j) & 1u)) {
+                  val = val * sc + sh;
+                  if (a.in_lrelu) val = hpvg_lrelu(val);
+                }
+                xs[(c * KT + dt) * PL + j * 256 + tid] = val;
+              }
+            }
+          }
+        }
+      }
+      HPVG_PH(0)
+      __syncthreads();
+      HPVG_PH(1)
+
       const AVec* wpt = reinterpret_cast<const AVec*>(a.wp) + ((long)(ch * TAPS) * a.mbtot + mb0) * 64 + lane;
       AVec av[MB];
 #pragma unroll
@@ -374,66 +255,124 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_pipe_kernel(const ConvFwdArg
           for (int dw = 0; dw < 3; ++dw) {
             wpt += (long)a.mbtot * 64;
             AVec an[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
             const float* xt = xl + dt * PL + dh * RS + dw;
-            // first k-step of the NEXT tap (past the chunk's last tap this is a harmless in-buffer read)
-            const float* xn = (dw < 2) ? xt + 1 : (dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1) * PL);
+            const float* xn = (dw < 2) ? xt + 1 : (dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1 < KT ? dt + 1 : 0) * PL);
 #pragma unroll
             for (int cp = 0; cp < CP; ++cp) {
               const float* nx = (cp + 1 < CP) ? xt + (2 * (cp + 1) * KT) * PL : xn;
 #pragma unroll
               for (int i = 0; i < NB; ++i) bv[(cp + 1) & 1][i] = nx[i * 128];
-              __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this k-step's MFMAs
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_setprio(1);
 #pragma unroll
               for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                   acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][cp], bv[cp & 1][i], acc[m][i], 0, 0, 0);
-              if (cp == 0) {
-                // next tap's A fragments and one plane of DMA staging, issued right AFTER this tap's first MFMA
-                // group: with LDS-DMA in flight hipcc waits vmcnt(0) (not a counted wait) at the first use of an
-                // ordinary load, so every VMEM op must be >= ~3/4 tap old when the next tap starts
-#pragma unroll
-                for (int m = 0; m < MB; ++m) an[m] = wpt[m * 64];
-                if (plnext < NPL) { dma_plane(plnext, nch, bufn); ++plnext; }
-              }
+              __builtin_amdgcn_s_setprio(0);
             }
 #pragma unroll
             for (int m = 0; m < MB; ++m) av[m] = an[m];
           }
         }
       }
-      while (plnext < NPL) { dma_plane(plnext, nch, bufn); ++plnext; }
+      HPVG_PH(2)
+    }
 
-      if (last_chunk) {
-        // ---- epilogue of the finished tile: bias, optional LeakyReLU, masked store; then reset the accumulators
+    if (ch_lo != 0 || ch_hi != a.nchunk) {
+      // ---- part of a tile: raw accumulators, register order (each store instruction writes 256 contiguous bytes)
+      const int seg = (tile == first_sk_tile) ? 0 : 1;
+      float* dst = a.skpart + ((long)(g * 2 + seg) * (MB * NB * 16)) * 256 + tid;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const int blk = wave + 4 * i;
-          const int q = blk * 32 + l31;
-          const int hh = q / RS, ww = q - hh * RS;
-          const int gh = ch0 + hh, gw = cw0 + ww;
-          const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
-          const long sp = (long)ct * HW + (long)gh * a.W + gw;
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
-          for (int m = 0; m < MB; ++m) {
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-              if (ok && co < a.Cout) {
-                float val = acc[m][i][e];
-                if (a.bias) val += a.bias[co];
-                if (a.out_lrelu) val = hpvg_lrelu(val);
-                a.y[((long)cb * a.Cout + co) * a.T * HW + sp] = val;
-              }
-              acc[m][i][e] = 0.f;
-            }
+          for (int e = 0; e < 16; ++e) dst[((m * NB + i) * 16 + e) * 256] = acc[m][i][e];
+      continue;
+    }
+    // ---- whole tile: bias (added AFTER the accumulation, as every torch conv backend does: a BatchNorm fed by a
+    // nearly constant channel amplifies the difference between (bias + sum) and (sum + bias) to percent level),
+    // optional LeakyReLU, masked store
+    float bias_r[MB][16];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        bias_r[m][e] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int blk = wave + 4 * i;
+      const int q = blk * 32 + l31;
+      const int hh = q / RS, ww = q - hh * RS;
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
+      if (!ok) continue;
+      const long sp = (long)t * HW + (long)gh * a.W + gw;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = (mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (co < a.Cout) {
+            float val = acc[m][i][e] + bias_r[m][e];
+            if (a.out_lrelu) val = hpvg_lrelu(val);
+            a.y[((long)b * a.Cout + co) * a.T * HW + sp] = val;
           }
         }
-        cb = nb_; ct = nt_; ch0 = nh0_; cw0 = nw0_;
       }
-      __syncthreads();  // staged buffer complete (the barrier's fence waits for pending LDS-DMA); current one free
-      cur ^= 1;
     }
+  }
+  HPVG_PH_END
+  HPVG_TRACE_END
+}
+
+// Finishes the tiles conv_mfma_kernel computed in parts: one workgroup per stream-K tile, partial slabs summed in
+// workgroup order, then the same epilogue.  Tiles computed whole by one workgroup were already stored: nothing to do.
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, int S, int MB, int NB) {
+  const int r = blockIdx.x;                   // stream-K tile
+  const int mi = blockIdx.y;                  // (m-tile, position block) of the accumulator slab
+  const int m = mi / NB, i = mi - m * NB;
+  const long Isk = (long)(a.ntl - a.skbase) * a.nchunk;
+  const long i0 = (long)r * a.nchunk, i1 = i0 + a.nchunk - 1;
+  const int g0 = (int)(((i0 + 1) * S + Isk - 1) / Isk) - 1;  // owner of the tile's first item
+  const int g1 = (int)(((i1 + 1) * S + Isk - 1) / Isk) - 1;  // ... and of its last
+  if (g0 == g1) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const SkTile tc = sk_decode_tile(a, a.skbase + r, MB);
+  const long HW = (long)a.H * a.W;
+  const int RS = a.RS;
+  const int blk = wave + 4 * i;
+  const int q = blk * 32 + l31;
+  const int hh = q / RS, ww = q - hh * RS;
+  const int gh = tc.h0 + hh, gw = tc.w0 + ww;
+  if (!(blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W)) return;
+  const long slab = (long)MB * NB * 16 * 256;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = 0.f;
+  for (int g = g0; g <= g1; ++g) {
+    const long st = (long)g * Isk / S, en = (long)(g + 1) * Isk / S;
+    if (st == en) continue;  // workgroup without stream-K items
+    const int seg = (st / a.nchunk == r) ? 0 : 1;
+    const float* src = a.skpart + (long)(g * 2 + seg) * slab + (long)mi * 16 * 256 + tid;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += src[e * 256];
+  }
+  const long sp = (long)tc.t * HW + (long)gh * a.W + gw;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = (tc.mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+    if (co >= a.Cout) continue;
+    float val = v[e];
+    if (a.bias) val += a.bias[co];
+    if (a.out_lrelu) val = hpvg_lrelu(val);
+    a.y[((long)tc.b * a.Cout + co) * a.T * HW + sp] = val;
   }
 }
 
@@ -467,30 +406,26 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   wp[idx] = val;
 }
 
-// y = act(bias[c] + sum_z part[z]) : finishing pass of the split-K launch (fixed summation order: reproducible)
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                                  float* __restrict__ y, int nsplit, long slab, int C, long S,
-                                                                  int lrelu) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < slab; i += (long)gridDim.x * 256) {
-    float v = part[i];
-    for (int z = 1; z < nsplit; ++z) v += part[(long)z * slab + i];
-    if (bias) v += bias[(i / S) % C];
-    if (lrelu) v = hpvg_lrelu(v);
-    y[i] = v;
-  }
-}
-
 inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
 
 struct Plan {
   int Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, nj;
-  size_t lds;      // bytes of ONE tile buffer (the pipelined kernel uses two)
-  bool pipelined;
+  size_t lds;  // bytes of the LDS tile buffer
 };
 
-// Tile planner: minimise (waves of workgroups over the chip) x (per-workgroup MFMA rounds).
-Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
+constexpr long CONV_SLOTS = 2L * HPVG_NUM_CU;  // co-resident workgroups: two per CU (256 VGPRs each, LDS <= 80 KB)
+
+// Tile planner.  streamk = true: the launch is S = min(items, 512) persistent workgroups that share the (tile, chunk)
+// items evenly (needs the partial-slab workspace).  streamk = false: one workgroup per tile, dealt out by the
+// hardware dispatcher (no workspace; grids of 1-5 tiles per slot are quantised - the reason stream-K exists).
+// Cost in us; constants fitted to measured launches (tools/perf_conv.py, stages 5-9, within 5 %): an item costs its
+// MFMA rounds (6.5 us per 32-position x 32-channel x 8-channel-chunk round when two workgroups share the CU's matrix
+// pipe, half that when alone) + ~8 us of staging / barrier work the co-resident workgroup does not hide + the input
+// planes it stages; tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block,
+// written by the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth).
+Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
   const int CC = conv_cc(Cin);
+  const int nchunk = hpvg_cdiv(Cin, CC);
   const int mbtot = hpvg_cdiv(Cout, 32);
   Plan best{};
   double best_cost = 1e300;
@@ -518,27 +453,35 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
         const int need = 128 * NB + 2 * RS + 2;
         if (PL < need) PL = need;
         const size_t lds = (size_t)CC * KT * PL * sizeof(float);
-        if (lds > (pipelined ? 78 : 160) * 1024) continue;
-        const int per_cu = pipelined ? 1 : (lds <= 80 * 1024 ? 2 : 1);
-        const long nwg = (long)B * T * nth * ntw * gridy;
-        const long slots = (long)HPVG_NUM_CU * per_cu;
+        if (lds > 80 * 1024) continue;
+        const long ntl = (long)B * T * nth * ntw * gridy;
+        const double stage_us = 0.0065 * (Th + 2) * RS;
         double cost;
-        if (pipelined) {
-          // persistent workgroups walk ceil(ntiles/S) tiles each; staging is hidden behind the MFMA loop
-          long S = slots / gridy;
-          if (S < 1) S = 1;
-          const long ntl = nwg / gridy;
-          const double rounds = (double)((ntl + S - 1) / S);
-          cost = rounds * ((double)NB * MB + 0.15) + 5e-4 * (double)nwg;
+        if (streamk) {
+          const long items_tot = ntl * nchunk;
+          const long S = items_tot < CONV_SLOTS ? items_tot : CONV_SLOTS;
+          const long ndp = ntl / S;
+          const long rem = (ntl - ndp * S) * nchunk;
+          const double items = (double)(ndp * nchunk) + (double)((rem + S - 1) / S);
+          const bool paired = S > HPVG_NUM_CU;
+          const double per_item = (double)NB * MB * (paired ? 6.5 : 3.4) + (paired ? 8.5 : 6.0) + stage_us;
+          const double tiles = (double)(ndp + (rem ? 1 : 0));
+          double parts = 0.0;
+          if (rem) {
+            parts = 1.0 + (double)rem / (double)S / (double)nchunk;
+            if (parts > 2.0) parts = 2.0;
+          }
+          cost = items * per_item + tiles * 0.8 * NB * MB + parts * 5.5 * NB * MB + 1e-4 * (double)ntl;
         } else {
-          const double waves = nwg <= slots ? 1.0 : (double)nwg / (double)slots;
-          // per-WG time ~ MFMA rounds (scaled by m-tiles) + fixed staging/sync overhead
-          const double per = (double)NB * MB + 0.6 + 0.002 * (Th + 2) * RS;
-          cost = waves * per + 5e-4 * (double)nwg;  // tie-break: fewer, fuller workgroups
+          // whole tiles per CU: pairs run together, an odd one runs alone at the end
+          const long per_cu = (ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
+          const double tile_paired = nchunk * ((double)NB * MB * 6.5 + 8.5 + stage_us) + 0.8 * NB * MB;
+          const double tile_alone = nchunk * ((double)NB * MB * 3.4 + 6.0 + stage_us) + 0.8 * NB * MB;
+          cost = (double)(per_cu / 2) * tile_paired + (double)(per_cu & 1) * tile_alone + 1e-4 * (double)ntl;
         }
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
-          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds, pipelined};
+          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds};
         }
       }
     }
@@ -547,52 +490,28 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
 }
 
 // The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).
-Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool pipelined) {
-  struct Key { int B, Cin, Cout, T, H, W, KT, pipe; };
+Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
+  struct Key { int B, Cin, Cout, T, H, W, KT, sk; };
   struct Entry { Key k; Plan p; };
   static thread_local Entry cache[128];
   static thread_local int used = 0;
-  const Key k{B, Cin, Cout, T, H, W, KT, pipelined ? 1 : 0};
+  const Key k{B, Cin, Cout, T, H, W, KT, streamk ? 1 : 0};
   for (int i = 0; i < used; ++i) {
     const Key& c = cache[i].k;
-    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.pipe == k.pipe)
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.sk == k.sk)
       return cache[i].p;
   }
-  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, pipelined);
+  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk);
   if (used < 128) cache[used++] = Entry{k, p};
   return p;
 }
 
-// Split-K decision for latency-bound grids: when the classic grid has fewer workgroups than the chip has slots, the
-// channel chunks of every tile are spread over blockIdx.z (each workgroup then runs a 1/nsplit-long serial chain) and
-// a finishing kernel sums the slabs.  Returns the number of splits (1 = no split).
-inline int conv_nsplit(const Plan& pc, int B, int T, int nchunk, int KT) {
-  const long nwg = (long)B * T * pc.nth * pc.ntw * pc.gridy;
-  // measured (bench.py per-stage it/s): pays for 3x3x3 convs on grids of ~100-500 workgroups; loses for 2-D convs
-  // (9 taps per chunk: the partial-slab write + finishing kernel outweigh the shorter chain) and for tiny grids
-  if (KT != 3 || nchunk < 2 || nwg >= 2L * HPVG_NUM_CU || nwg < 128) return 1;
-  long want = (3L * HPVG_NUM_CU + nwg - 1) / nwg;  // aim at ~3 workgroups per CU
-  if (want > 4) want = 4;
-  if (want > nchunk) want = nchunk;
-  if (want < 2) return 1;
-  const int cps = hpvg_cdiv(nchunk, (int)want);
-  return hpvg_cdiv(nchunk, cps);
-}
-
+// Launch of S workgroups.  The dynamic LDS request is padded to 56 KB so that a third workgroup never fits on a CU:
+// the persistent grid is sized for exactly two.
+constexpr size_t CONV_MIN_LDS = 56 * 1024;
 template <int CC, int KT, int MB, int NB>
-int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
-  static bool attr_set = false, attr_set2 = false;
-  if (p.pipelined) {
-    auto kern = conv_mfma_pipe_kernel<CC, KT, MB, NB>;
-    if (!attr_set2) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-          hipSuccess)
-        (void)hipGetLastError();
-      attr_set2 = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.S, p.gridy), dim3(256), 2 * p.lds, s, a);
-    return hpvg_launch_status();
-  }
+int launch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+  static bool attr_set = false;
   auto kern = conv_mfma_kernel<CC, KT, MB, NB>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -600,25 +519,39 @@ int launch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
       (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles, p.gridy, a.part ? hpvg_cdiv(a.nchunk, a.cps) : 1), dim3(256), p.lds, s, a);
-  return hpvg_launch_status();
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), p.lds < CONV_MIN_LDS ? CONV_MIN_LDS : p.lds, s, a);
+  int rc = hpvg_launch_status();
+  if (rc != HPVG_OK) return rc;
+  const int nsk = a.ntl - a.skbase;
+  if (nsk > 0) {
+    hipLaunchKernelGGL(conv_fixup_kernel, dim3(nsk, MB * NB), dim3(256), 0, s, a, S, MB, NB);
+    rc = hpvg_launch_status();
+  }
+  return rc;
 }
 
 template <int CC, int KT>
-int dispatch_conv(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
+int dispatch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   if (p.MB == 2) {
     switch (p.NB) {
-      case 1: return launch_conv<CC, KT, 2, 1>(a, p, s);
-      case 2: return launch_conv<CC, KT, 2, 2>(a, p, s);
-      default: return launch_conv<CC, KT, 2, 4>(a, p, s);
+      case 1: return launch_conv<CC, KT, 2, 1>(a, p, S, s);
+      case 2: return launch_conv<CC, KT, 2, 2>(a, p, S, s);
+      default: return launch_conv<CC, KT, 2, 4>(a, p, S, s);
     }
   }
   switch (p.NB) {
-    case 1: return launch_conv<CC, KT, 1, 1>(a, p, s);
-    case 2: return launch_conv<CC, KT, 1, 2>(a, p, s);
-    default: return launch_conv<CC, KT, 1, 4>(a, p, s);
+    case 1: return launch_conv<CC, KT, 1, 1>(a, p, S, s);
+    case 2: return launch_conv<CC, KT, 1, 2>(a, p, S, s);
+    default: return launch_conv<CC, KT, 1, 4>(a, p, S, s);
   }
 }
+
+// stream-K grid for a plan: all co-resident slots, or one workgroup per item when there are fewer items than slots
+inline int conv_sk_grid(int ntl, int nchunk) {
+  const long items = (long)ntl * nchunk;
+  return (int)(items < CONV_SLOTS ? items : CONV_SLOTS);
+}
+inline size_t conv_sk_ws_bytes(const Plan& p, int S) { return (size_t)S * 2 * p.MB * p.NB * 16 * 256 * sizeof(float); }
 
 }  // namespace
 
@@ -653,6 +586,8 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 // y[b][o][t][h][w] = bias[o] + sum_{c,tap} Wp[o][c][tap] * f(x)[b][c][t+dt-pt][h+dh-1][w+dw-1]
 // f = identity, or (in_scale[c]*x + in_shift[c]) followed by LeakyReLU(0.2) when in_lrelu (zero padding
 // is applied AFTER f, as in the reference where f is the previous block's BatchNorm+LeakyReLU output).
+// ws / ws_bytes: hpvg_conv_fwd_ws_bytes() of scratch enables the stream-K schedule; with ws = NULL (or too small)
+// the same kernel runs one workgroup per tile.
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
                       int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
                       int W, int KT, void* stream) {
@@ -660,62 +595,47 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
-  // development knob: HPVG_CONV_PIPE = 0 classic (no split) / 1 pipelined persistent / 3 classic + split-K; default auto
-  static const int force = [] { const char* e = getenv("HPVG_CONV_PIPE"); return e ? atoi(e) : -1; }();
-  // Variant choice (measured, tools/perf_conv.py).  Chip-filling grids: classic kernel, two co-resident workgroups per
-  // CU hide each other's staging.  Latency-bound grids (< 512 workgroups): split the channel chunks over blockIdx.z
-  // (split-K) when the caller provided workspace, else the software-pipelined persistent kernel.
-  const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
-  const int nchunk_c = hpvg_cdiv(Cin, conv_cc(Cin));
-  int nsplit = conv_nsplit(pc, B, T, nchunk_c, KT);
-  const size_t slab = (size_t)B * Cout * T * H * W;
-  if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * slab * sizeof(float))) nsplit = 1;
-  if (force == 0 || force == 1) nsplit = 1;
-  bool pipelined = false;
-  if (nsplit == 1 && in_scale == nullptr) pipelined = (long)B * T * pc.nth * pc.ntw * pc.gridy <= 2L * HPVG_NUM_CU;
-  if (force == 0 || force == 3) pipelined = false;
-  if (force == 1 && in_scale == nullptr) pipelined = true;
-  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, pipelined);
+  // development knob: HPVG_CONV_SK=0 forces the one-workgroup-per-tile schedule
+  static const bool sk_off = [] { const char* e = getenv("HPVG_CONV_SK"); return e && atoi(e) == 0; }();
+  const int CC = conv_cc(Cin);
+  const int nchunk = hpvg_cdiv(Cin, CC);
+  bool streamk = !sk_off && ws != nullptr;
+  Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  int ntl = B * T * p.nth * p.ntw * p.gridy;
+  if (streamk && ws_bytes < conv_sk_ws_bytes(p, conv_sk_grid(ntl, nchunk))) {
+    streamk = false;
+    p = plan_conv(B, Cin, Cout, T, H, W, KT, false);
+    ntl = B * T * p.nth * p.ntw * p.gridy;
+  }
   ConvFwdArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.nth = p.nth; a.ntw = p.ntw; a.nblocks = p.nblocks;
-  const int CC = conv_cc(Cin);
-  a.nchunk = hpvg_cdiv(Cin, CC);
-  a.ntiles = B * T * p.nth * p.ntw;
+  a.nchunk = nchunk;
   a.mbtot = hpvg_cdiv(Cout, 32);
   a.nj = p.nj;
-  {
-    long S = HPVG_NUM_CU / p.gridy;
-    if (S < 1) S = 1;
-    a.S = (int)(a.ntiles < S ? a.ntiles : S);
-  }
   a.in_lrelu = in_lrelu; a.out_lrelu = out_lrelu;
-  a.part = nsplit > 1 ? (float*)ws : nullptr;
-  a.part_stride = (long)slab;
-  a.cps = nsplit > 1 ? hpvg_cdiv(a.nchunk, nsplit) : a.nchunk;
+  a.gridy = p.gridy;
+  a.ntl = ntl;
+  const int S = streamk ? conv_sk_grid(ntl, nchunk) : ntl;  // S = ntl: one data-parallel round, no stream-K part
+  a.ndp = ntl / S;
+  a.skbase = a.ndp * S;
+  a.skpart = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
-  int rc;
-  if (CC == 8) rc = KT == 3 ? dispatch_conv<8, 3>(a, p, s) : dispatch_conv<8, 1>(a, p, s);
-  else rc = KT == 3 ? dispatch_conv<4, 3>(a, p, s) : dispatch_conv<4, 1>(a, p, s);
-  if (rc != HPVG_OK || nsplit == 1) return rc;
-  long nb = (long)((slab + 1023) / 1024);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)ws, bias, y,
-                     hpvg_cdiv(a.nchunk, a.cps), (long)slab, Cout, (long)T * H * W, out_lrelu);
-  return hpvg_launch_status();
+  if (CC == 8) return KT == 3 ? dispatch_conv<8, 3>(a, p, S, s) : dispatch_conv<8, 1>(a, p, S, s);
+  return KT == 3 ? dispatch_conv<4, 3>(a, p, S, s) : dispatch_conv<4, 1>(a, p, S, s);
 }
 
-// workspace the split-K path of hpvg_conv_fwd_f32 wants for this shape (0: the shape never splits)
+// scratch the stream-K schedule of hpvg_conv_fwd_f32 wants for this shape
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
-  const Plan pc = plan_conv(B, Cin, Cout, T, H, W, KT, false);
-  const int nsplit = conv_nsplit(pc, B, T, hpvg_cdiv(Cin, conv_cc(Cin)), KT);
-  return nsplit > 1 ? (size_t)nsplit * B * Cout * T * H * W * sizeof(float) : 0;
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
+  if (p.Th == 0) return 0;
+  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nth * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin))));
 }
 
-// Debug/introspection: the tile plan the launcher will use (for tests and DESIGN.md tables).
+// Debug/introspection: the tile plan of the stream-K launch (for tests and DESIGN.md tables).
 // out[0..9] = Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds_bytes, ntiles
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
   if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
@@ -724,5 +644,14 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
   out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
   return HPVG_OK;
 }
+
+#ifdef HPVG_TRACE
+int hpvg_debug_phase_read(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 4 * n) == hipSuccess ? 0 : -4;
+}
+int hpvg_debug_trace_read(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 4 * n) == hipSuccess ? 0 : -4;
+}
+#endif
 
 }  // extern "C"

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libhpvg.so")
+LIB_PATH = os.environ.get("HPVG_LIB") or os.path.join(_HERE, "libhpvg.so")  # HPVG_LIB: development builds (tools/trace_conv.py)
 HEADER_PATH = os.path.join(_ROOT, "include", "hpvg.h")
 
 _lib = None

@@ -36,8 +36,10 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 /* y = conv(f(x), wp) + bias; f = identity or LeakyReLU_opt(in_scale[c]*x + in_shift[c]) applied before zero padding
  * (fused BatchNorm-apply of the producing ConvBlock3D, networks_3d.py:54-55); out_lrelu: LeakyReLU(0.2) epilogue
  * (ConvBlock3DSN, networks_3d.py:59-70). bias may be NULL. */
-/* ws (optional, may be NULL): scratch for the split-K path taken by latency-bound shapes; size from
- * hpvg_conv_fwd_ws_bytes (0 = this shape never splits).  Without it those shapes run unsplit (slower, same result). */
+/* ws (optional, may be NULL): scratch of hpvg_conv_fwd_ws_bytes() bytes for the stream-K schedule (512 persistent
+ * workgroups share the (tile, channel-chunk) items evenly; tiles cut across workgroups pass through ws as partial sums
+ * and are finished in fixed order).  Without it the same kernel runs one workgroup per tile: slower on grids of 1-5
+ * tiles per CU slot, results equal up to fp32 summation order. */
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT);
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
                       int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,

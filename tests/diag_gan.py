@@ -22,6 +22,7 @@ for it, (rec, out, netG, netD, trainer) in enumerate(run_hip_stage(fx)):
                 print("D_after %-32s maxabs %.3e  count(>1e-5) %d / %d" % (k, d, n, v.numel()))
     gotG = flat_to_named(out["gradG_flat"], trainer.arenaG, netG)
     errs = sorted(((rel_err(gotG[k], g), k) for k, g in rec["gradsG"].items() if g is not None), reverse=True)
+    print("gradG worst 6 (all)", errs[:6])
     errs = [e for e in errs if not e[1].endswith("conv.bias")]
     print("gradG worst 8 (no conv.bias)", errs[:8])
     print("total_norm rel", rel_err(out["clip_info"][1], rec["total_norm"]))
@@ -31,6 +32,7 @@ from smoke_step import _oracle_first_iter
 want = _oracle_first_iter(fx)
 rec = fx["iters"][0]
 errs = sorted(((rel_err(want["gradsG"][k], g), k) for k, g in rec["gradsG"].items() if g is not None), reverse=True)
+print("ORACLE-vs-golden gradG worst 6 (all)", errs[:6])
 errs = [e for e in errs if not e[1].endswith("conv.bias")]
 print("ORACLE-vs-golden gradG worst 8", errs[:8], "threads", torch.get_num_threads())
 if "gradsD" in rec:

@@ -53,6 +53,37 @@ def test_conv_fwd_bwd(ops, B, Cin, Cout, sp):
     assert_close(dbd, db, RTOL, "conv.db")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,sp", [
+    (2, 64, 64, (7, 72, 129)),   # 560 tiles: one data-parallel round + 48 stream-K tiles cut over 512 workgroups
+    (2, 64, 64, (5, 45, 81)),    # every workgroup owns a fraction of a tile (all tiles finished by the fix-up kernel)
+    (1, 128, 70, (3, 30, 50)),   # 16 channel chunks, ragged Cout
+    (2, 64, 64, (200, 300)),     # 2-D, several rounds
+    (2, 24, 3, (3, 64, 100)),    # narrow output, 3 chunks
+])
+def test_conv_stream_k_schedules_and_plain_launch(ops, B, Cin, Cout, sp):
+    """The stream-K schedule (workspace given) and the one-workgroup-per-tile launch (ws = NULL) against the oracle, on
+    shapes whose tiles are split across workgroups; the two launches agree to fp32 summation order."""
+    import ctypes
+    from hp_vae_gan_amd import lib as hplib
+    nd = len(sp)
+    x = _rand(B, Cin, *sp, seed=11)
+    w = _rand(Cout, Cin, *([3] * nd), seed=12, scale=0.05)
+    b = _rand(Cout, seed=13)
+    want = O.conv(x, w, b)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y_sk = ops.conv_fwd_raw(xd, wd, bd)
+    assert_close(y_sk, want, RTOL, "conv.streamk")
+    Bq, C, T, H, W = ops.geom(xd)
+    KT = 3 if nd == 3 else 1
+    assert hplib.call("hpvg_conv_fwd_ws_bytes", Bq, Cin, Cout, T, H, W, KT) > 0
+    wp = ops.pack_weight(wd, False)
+    y_pl = torch.full_like(y_sk, float("nan"))
+    hplib.call("hpvg_conv_fwd_f32", hplib.ptr(xd), hplib.ptr(wp), hplib.ptr(bd), None, None, 0, hplib.ptr(y_pl), 0, None,
+               ctypes.c_size_t(0), Bq, Cin, Cout, T, H, W, KT, hplib.stream())
+    assert_close(y_pl, want, RTOL, "conv.plain")
+    assert_close(y_pl, y_sk, 1e-5, "conv.plain-vs-streamk")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
 def test_conv_lrelu_epilogue_and_affine_prologue(ops, B, Cin, Cout, sp):
     nd = len(sp)

@@ -6,7 +6,7 @@ import torch
 import hp_vae_gan_amd
 from hp_vae_gan_amd import ops
 
-SHAPES = {0: (4, 18, 33), 3: (5, 36, 65), 5: (5, 57, 102), 6: (7, 72, 129), 7: (7, 91, 162), 8: (7, 114, 204), 9: (13, 144, 256)}
+SHAPES = {0: (4, 18, 33), 1: (4, 23, 41), 2: (4, 29, 52), 3: (5, 36, 65), 4: (5, 45, 81), 5: (5, 57, 102), 6: (7, 72, 129), 7: (7, 91, 162), 8: (7, 114, 204), 9: (13, 144, 256)}
 stage = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 T, H, W = SHAPES[stage]
@@ -32,6 +32,9 @@ def bench(name, fn, fl=flops):
 
 
 bench("conv_fwd 64->64", lambda: ops.conv_fwd_raw(x, w, b))
+sc = torch.rand(64, device=dev) + 0.5
+sh = torch.randn(64, device=dev) * 0.1
+bench("conv_fwd 64->64 fused BN+lrelu in", lambda: ops.conv_fwd_raw(x, w, b, in_affine=(sc, sh), in_lrelu=True))
 bench("conv_bwd_data 64->64", lambda: ops.conv_fwd_raw(dy, w, None, flip=True))
 bench("conv_bwd_weight 64->64", lambda: ops.conv_bwd_weight_raw(dy, x, w.shape))
 w3 = torch.randn(3, 64, 3, 3, 3, device=dev) * 0.05
