@@ -153,11 +153,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
 
     // ---- per-thread staging slots: position p = j*256+tid inside one (Th+2) x RS input plane
     int gofs[NJMAX];
+    unsigned bofs[NJMAX];  // the same as a byte offset (planes are < 4 GB)
     unsigned okmask = 0, wmask = 0;
 #pragma unroll
     for (int j = 0; j < NJMAX; ++j) {
       const int p = j * 256 + tid;
       gofs[j] = 0;
+      bofs[j] = 0;
       if (j < a.nj && p < plload) {
         const int hh = p / RS, ww = p - hh * RS;
         const int gh = h0 + hh - 1, gw = w0 + ww - 1;
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
         if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
           okmask |= 1u << j;
           gofs[j] = gh * a.W + gw;
+          bofs[j] = (unsigned)gofs[j] * 4u;
         }
       }
     }
@@ -182,19 +185,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       first_stage = false;
       HPVG_PH(3)
       if (!prologue) {
+        // LDS-DMA staging with as little VALU work as possible (a co-resident wave with MFMAs queued keeps the SIMD's
+        // VALU port busy, which stretched a select-per-load version of this loop from 2.4 to 15-20 us per chunk): the
+        // per-lane byte offsets are tile constants, the plane base is scalar, out-of-image lanes are switched off by
+        // EXEC and their LDS words are zeroed once per tile (no load ever writes them).
+        const bool first_chunk = ch == ch_lo;
 #pragma unroll 1
         for (int pl = 0; pl < CC * KT; ++pl) {
           const int c = pl / KT, dt = pl - c * KT;
           const int cg = ch * CC + c;
           const int tt = t + dt - (KT == 3 ? 1 : 0);
           const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
-          const float* src = a.x + (((long)b * a.Cin + (valid ? cg : 0)) * a.T + (valid ? tt : 0)) * HW;
           float* dst = xs + pl * PL + wave * 64;
+          if (valid) {
+            const char* src = reinterpret_cast<const char*>(a.x + (((long)b * a.Cin + cg) * a.T + tt) * HW);
 #pragma unroll
-          for (int j = 0; j < NJMAX; ++j)
-            if ((wmask >> j) & 1u)
-              __builtin_amdgcn_global_load_lds((gptr_t)((valid && ((okmask >> j) & 1u)) ? src + gofs[j] : g_zero_word),
-                                               (lptr_t)(dst + j * 256), 4, 0, 0);
+            for (int j = 0; j < NJMAX; ++j)
+              if ((okmask >> j) & 1u)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + bofs[j]), (lptr_t)(dst + j * 256), 4, 0, 0);
+            if (first_chunk) {
+#pragma unroll
+              for (int j = 0; j < NJMAX; ++j)
+                if (((wmask & ~okmask) >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
+            }
+          } else if (first_chunk || cg >= a.Cin) {
+            // a plane outside the clip (t) stays zero for the whole tile; a channel past Cin only exists in the last chunk
+#pragma unroll
+            for (int j = 0; j < NJMAX; ++j)
+              if ((wmask >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
+          }
         }
       } else {
 #pragma unroll 2

@@ -284,12 +284,16 @@ def num_body(P):
     return k
 
 
-def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True):
-    """GeneratorHPVAEGAN.forward.  `noises` is an iterator yielding the N(0,1) draws in reference order
-    (reparameterisation eps first, then one tensor per noisy level), or a callable(shape) -> tensor."""
+def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True,
+                      sample_init=None):
+    """GeneratorHPVAEGAN.forward (networks_3d.py:367-406).  `noises` is an iterator yielding the N(0,1) draws in
+    reference order (reparameterisation eps first, then one tensor per noisy level), or a callable(shape) -> tensor.
+    sample_init = (start_index, tensor): the refinement restarts from that level's tensor (generation path)."""
     def draw(shape):
         return noises(tuple(shape)) if callable(noises) else next(noises)
 
+    if sample_init is not None:
+        assert num_body(P) > sample_init[0], "Strating index must be lower than # of body blocks"
     if noise_init is None:
         mu, logvar = encoder_forward(video, P, opt, training)
         eps = draw(mu.shape)
@@ -297,8 +301,8 @@ def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='ran
     else:
         z = noise_init
     vae_out = torch.tanh(_stack7(z, P, 'decoder', opt.num_layer))
-    x = vae_out
-    for idx in range(num_body(P)):
+    start, x = (0, vae_out) if sample_init is None else (sample_init[0], sample_init[1])
+    for idx in range(start, num_body(P)):
         if opt.vae_levels == idx + 1 and not opt.train_all:
             x = x.detach()
             if idx == 0:

@@ -282,6 +282,44 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed):
     return fx
 
 
+def run_sampling(images, nets, opt, dims, scale_idx, seed):
+    """The generation path of networks_3d.py:367-387 as the trainers' preview code drives it (train_video.py:225-241:
+    no_grad, modules left in train mode): (a) a full random pass from a latent, (b) a restart from an intermediate
+    level through sample_init=(index, tensor)."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    images.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(scale_idx):
+        netG.init_next_stage()
+    perturb(netG, gen)
+
+    def shape(i):
+        w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+        if dims == 3:
+            _, td, _ = images.get_fps_td_by_index(i, opt)
+            return [td, int(w * opt.ar), w]
+        return [int(w * opt.ar), w]
+
+    noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx + 1)]
+    fx = {'opt': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, bool, list, str))},
+          'dims': dims, 'scale_idx': scale_idx, 'G_init': sd_clone(netG), 'noise_amps': list(noise_amps), 'calls': []}
+    z_size = [opt.batch_size, opt.latent_dim, *shape(0)]
+    start = 1
+    prev = torch.rand(opt.batch_size, 3, *shape(start), generator=gen) * 2 - 1
+    for sample_init in (None, (start, prev)):
+        with Recorder() as rec, torch.no_grad():
+            noise_init = images.generate_noise(size=z_size, device='cpu')
+            x, vae_out = netG(noise_init, noise_amps, noise_init=noise_init,
+                              sample_init=None if sample_init is None else (sample_init[0], sample_init[1].clone()), mode="rand")
+        fx['calls'].append({'sample_start': None if sample_init is None else sample_init[0],
+                            'sample_tensor': None if sample_init is None else sample_init[1],
+                            'noise_init': rec.normals[0], 'noises': rec.normals[1:], 'x': x.clone(), 'vae_out': vae_out.clone(),
+                            'G_after': sd_clone(netG)})
+    return fx
+
+
 def op_fixtures(images, n3, n2, losses, mutils):
     """Per-op fixtures on odd shapes (halo bugs), produced by the reference's own block classes."""
     gen = torch.Generator().manual_seed(7)
@@ -381,18 +419,26 @@ def table_fixtures(images):
 
 
 def main():
+    """usage: make_golden.py [fixture-name ...]   (default: all)"""
     images, n3, n2, losses, mutils = load_reference()
     torch.set_num_threads(1)
-    with open(os.path.join(OUT, 'tables.json'), 'w') as f:
-        json.dump(table_fixtures(images), f, indent=1)
-    torch.save(op_fixtures(images, n3, n2, losses, mutils), os.path.join(OUT, 'ops.pt'))
-    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 1, 1, seed=100), os.path.join(OUT, 'step3d_vae_s1.pt'))
-    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 0, 1, seed=101), os.path.join(OUT, 'step3d_vae_s0.pt'))
-    torch.save(run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 3, 1, seed=102), os.path.join(OUT, 'step3d_gan_s3.pt'))
-    torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=1), 2, 2, 2, seed=103), os.path.join(OUT, 'step2d_gan_s2.pt'))
-    torch.save(run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=104), os.path.join(OUT, 'step2d_vae_s1.pt'))
-    torch.save(run_baseline_steps(images, n3, mutils, make_opt(Dsteps=2, Gsteps=1, alpha=10.0, train_depth=1), 2, 1, seed=105),
-               os.path.join(OUT, 'baseline3d_s2.pt'))
+    jobs = {
+        'ops.pt': lambda: op_fixtures(images, n3, n2, losses, mutils),
+        'step3d_vae_s1.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 1, 1, seed=100),
+        'step3d_vae_s0.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 0, 1, seed=101),
+        'step3d_gan_s3.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 3, 1, seed=102),
+        'step2d_gan_s2.pt': lambda: run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=1), 2, 2, 2, seed=103),
+        'step2d_vae_s1.pt': lambda: run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=104),
+        'baseline3d_s2.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=2, Gsteps=1, alpha=10.0, train_depth=1), 2, 1, seed=105),
+        'sample3d_s3.pt': lambda: run_sampling(images, n3, make_opt(vae_levels=2), 3, 3, seed=106),
+    }
+    want = sys.argv[1:] or ['tables.json'] + list(jobs)
+    if 'tables.json' in want:
+        with open(os.path.join(OUT, 'tables.json'), 'w') as f:
+            json.dump(table_fixtures(images), f, indent=1)
+    for name in want:
+        if name in jobs:
+            torch.save(jobs[name](), os.path.join(OUT, name))
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -50,6 +50,34 @@ def test_train_step_matches_reference(fname):
                 assert_close(sdD[k].float(), v.float(), RTOL, "%s[%d].D_after.%s" % (fname, it, k), atol=2 * lr)
 
 
+def test_sampling_path_matches_reference():
+    """Generation path (forward with noise_init / sample_init, networks_3d.py:367-387) as the trainers' previews run it
+    (no_grad, train-mode BatchNorm): outputs and the moved running statistics against the reference fixture."""
+    from helpers import NoiseFeed, hip_opt
+    from hp_vae_gan_amd.modules import networks_3d
+    fx = load_golden("sample3d_s3.pt")
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], fx["dims"], fx["scale_idx"], dev)
+    netG = networks_3d.GeneratorHPVAEGAN(opt)
+    for _ in range(fx["scale_idx"]):
+        netG.init_next_stage()
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    for call in fx["calls"]:
+        netG.noise_source = NoiseFeed(call["noises"], dev)
+        si = None if call["sample_start"] is None else (call["sample_start"], call["sample_tensor"].to(dev))
+        with torch.no_grad():
+            x, vae_out = netG(call["noise_init"].to(dev), fx["noise_amps"], noise_init=call["noise_init"].to(dev), sample_init=si,
+                              mode="rand")
+        assert_close(x, call["x"], RTOL, "sample.x")
+        assert_close(vae_out, call["vae_out"], RTOL, "sample.vae_out")
+        sd = netG.state_dict()
+        for k, v in call["G_after"].items():
+            assert_close(sd[k].float(), v.float(), RTOL, "sample.G_after." + k, atol=1e-6)
+    with pytest.raises(AssertionError):
+        netG(None, fx["noise_amps"], noise_init=fx["calls"][0]["noise_init"].to(dev), sample_init=(3, fx["calls"][1]["sample_tensor"].to(dev)))
+
+
 def test_smoke_entry():
     from smoke_step import run_smoke
     run_smoke()

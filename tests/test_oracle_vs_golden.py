@@ -172,6 +172,28 @@ def test_train_step(fname):
                 assert_close(PD[k].float(), v.float(), 1e-4, fname + ".D_after." + k, atol=2 * lr)
 
 
+def test_sampling_path():
+    """Generation (networks_3d.py:367-387 with noise_init / sample_init), as the trainers' previews run it: train-mode
+    BatchNorm under no_grad, so the running statistics move."""
+    fx = load_golden("sample3d_s3.pt")
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    P = oracle_state(fx["G_init"], requires_grad=False)
+    for call in fx["calls"]:
+        si = None if call["sample_start"] is None else (call["sample_start"], call["sample_tensor"].clone())
+        with torch.no_grad():
+            x, vae_out = O.generator_forward(P, opt, fx["dims"], call["noise_init"], fx["noise_amps"], noise_init=call["noise_init"],
+                                             mode="rand", noises=iter(call["noises"]), sample_init=si)
+        assert_close(x, call["x"], 2e-5, "sample.x")
+        assert_close(vae_out, call["vae_out"], 2e-5, "sample.vae_out")
+        for k, v in call["G_after"].items():
+            assert_close(P[k].float(), v.float(), 2e-5, "sample.G_after." + k, atol=1e-7)
+    with pytest.raises(AssertionError):
+        O.generator_forward(P, opt, fx["dims"], None, fx["noise_amps"], noise_init=fx["calls"][0]["noise_init"],
+                            sample_init=(3, fx["calls"][1]["sample_tensor"]))
+
+
 def test_c_restatement_of_conv_matches():
     """oracle/conv_direct.c (plain C loops) against the oracle's torch conv on small 3-D and 2-D cases."""
     import ctypes
