@@ -104,13 +104,122 @@ __device__ __forceinline__ SkTile sk_decode_tile(const ConvFwdArgs& a, int tile,
   return c;
 }
 
+// Per-thread staging slots of a tile: position p = j*256+tid inside one (Th+2) x RS input plane (zero padded).
+struct StageSlots {
+  int gofs[NJMAX];        // element offset inside a (c,t) plane (valid lanes)
+  unsigned bofs[NJMAX];   // the same in bytes (planes are < 4 GB)
+  unsigned okmask, wmask; // bit j: slot j lies inside the image / inside the staged plane
+};
+__device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int h0, int w0, int tid) {
+  StageSlots sl;
+  sl.okmask = 0;
+  sl.wmask = 0;
+  const int RS = a.RS, plload = (a.Th + 2) * RS;
+#pragma unroll
+  for (int j = 0; j < NJMAX; ++j) {
+    const int p = j * 256 + tid;
+    sl.gofs[j] = 0;
+    sl.bofs[j] = 0;
+    if (j < a.nj && p < plload) {
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      sl.wmask |= 1u << j;
+      if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+        sl.okmask |= 1u << j;
+        sl.gofs[j] = gh * a.W + gw;
+        sl.bofs[j] = (unsigned)sl.gofs[j] * 4u;
+      }
+    }
+  }
+  return sl;
+}
+
+// Stage channel chunk `ch` (CC channels x KT time planes) of the tile of sample b / output plane t into xs.
+template <int CC, int KT>
+__device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs, const StageSlots& sl, int ch, bool first_chunk,
+                                                 int b, int t, int tid, int wave) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const long HW = (long)a.H * a.W;
+  const int PL = a.PL;
+  if (a.in_scale == nullptr) {
+    // LDS-DMA staging with as little VALU work as possible (a co-resident wave with MFMAs queued keeps the SIMD's
+    // VALU port busy, which stretched a select-per-load version of this loop from 2.4 to 15-20 us per chunk): the
+    // per-lane byte offsets are tile constants, the plane base is scalar, out-of-image lanes are switched off by
+    // EXEC and their LDS words are zeroed once per tile (no load ever writes them).
+#pragma unroll 1
+    for (int pl = 0; pl < CC * KT; ++pl) {
+      const int c = pl / KT, dt = pl - c * KT;
+      const int cg = ch * CC + c;
+      const int tt = t + dt - (KT == 3 ? 1 : 0);
+      const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
+      float* dst = xs + pl * PL + wave * 64;
+      if (valid) {
+        const char* src = reinterpret_cast<const char*>(a.x + (((long)b * a.Cin + cg) * a.T + tt) * HW);
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j)
+          if ((sl.okmask >> j) & 1u)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + sl.bofs[j]), (lptr_t)(dst + j * 256), 4, 0, 0);
+        if (first_chunk) {
+#pragma unroll
+          for (int j = 0; j < NJMAX; ++j)
+            if (((sl.wmask & ~sl.okmask) >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
+        }
+      } else if (first_chunk || cg >= a.Cin) {
+        // a plane outside the clip (t) stays zero for the whole tile; a channel past Cin only exists in the last chunk
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j)
+          if ((sl.wmask >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
+      }
+    }
+  } else {
+    // through registers: the producer's BatchNorm-apply (+ LeakyReLU) is fused into the load
+#pragma unroll 2
+    for (int c = 0; c < CC; ++c) {
+      const int cg = ch * CC + c;
+      const bool cok = cg < a.Cin;
+      float sc = 1.f, sh = 0.f;
+      if (cok) {
+        sc = a.in_scale[cg];
+        sh = a.in_shift[cg];
+      }
+      float v[KT][NJMAX];
+#pragma unroll
+      for (int dt = 0; dt < KT; ++dt) {
+        const int tt = t + dt - (KT == 3 ? 1 : 0);
+        const bool tok = cok && tt >= 0 && tt < a.T;
+        const float* src = a.x + (((long)b * a.Cin + (cok ? cg : 0)) * a.T + (tok ? tt : 0)) * HW;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j) {
+          const bool ld = tok && ((sl.okmask >> j) & 1u);
+          v[dt][j] = ld ? src[sl.gofs[j]] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < KT; ++dt) {
+        const int tt = t + dt - (KT == 3 ? 1 : 0);
+        const bool tok = cok && tt >= 0 && tt < a.T;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j) {
+          if ((sl.wmask >> j) & 1u) {
+            float val = v[dt][j];
+            if (tok && ((sl.okmask >> j) & 1u)) {
+              val = val * sc + sh;
+              if (a.in_lrelu) val = hpvg_lrelu(val);
+            }
+            xs[(c * KT + dt) * PL + j * 256 + tid] = val;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int CC, int KT, int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) {
   constexpr int CP = CC / 2;
   constexpr int TAPS = KT * 9;
   typedef typename AVecT<CP>::type AVec;
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) float xs[];
 
   const int tid = threadIdx.x;
@@ -119,8 +228,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
   const int half = lane >> 5, l31 = lane & 31;
   const long HW = (long)a.H * a.W;
   const int RS = a.RS, PL = a.PL;
-  const int plload = (a.Th + 2) * RS;
-  const bool prologue = a.in_scale != nullptr;
   const float* xl = xs + half * KT * PL + l31 + wave * 32;
 
   HPVG_TRACE_BEGIN
@@ -151,26 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
     const SkTile tc = sk_decode_tile(a, tile, MB);
     const int b = tc.b, t = tc.t, h0 = tc.h0, w0 = tc.w0, mb0 = tc.mb0;
 
-    // ---- per-thread staging slots: position p = j*256+tid inside one (Th+2) x RS input plane
-    int gofs[NJMAX];
-    unsigned bofs[NJMAX];  // the same as a byte offset (planes are < 4 GB)
-    unsigned okmask = 0, wmask = 0;
-#pragma unroll
-    for (int j = 0; j < NJMAX; ++j) {
-      const int p = j * 256 + tid;
-      gofs[j] = 0;
-      bofs[j] = 0;
-      if (j < a.nj && p < plload) {
-        const int hh = p / RS, ww = p - hh * RS;
-        const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-        wmask |= 1u << j;
-        if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
-          okmask |= 1u << j;
-          gofs[j] = gh * a.W + gw;
-          bofs[j] = (unsigned)gofs[j] * 4u;
-        }
-      }
-    }
+    const StageSlots sl = conv_stage_slots(a, h0, w0, tid);
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -184,77 +272,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       if (!first_stage) __syncthreads();  // every wave is done reading the previous chunk
       first_stage = false;
       HPVG_PH(3)
-      if (!prologue) {
-        // LDS-DMA staging with as little VALU work as possible (a co-resident wave with MFMAs queued keeps the SIMD's
-        // VALU port busy, which stretched a select-per-load version of this loop from 2.4 to 15-20 us per chunk): the
-        // per-lane byte offsets are tile constants, the plane base is scalar, out-of-image lanes are switched off by
-        // EXEC and their LDS words are zeroed once per tile (no load ever writes them).
-        const bool first_chunk = ch == ch_lo;
-#pragma unroll 1
-        for (int pl = 0; pl < CC * KT; ++pl) {
-          const int c = pl / KT, dt = pl - c * KT;
-          const int cg = ch * CC + c;
-          const int tt = t + dt - (KT == 3 ? 1 : 0);
-          const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
-          float* dst = xs + pl * PL + wave * 64;
-          if (valid) {
-            const char* src = reinterpret_cast<const char*>(a.x + (((long)b * a.Cin + cg) * a.T + tt) * HW);
-#pragma unroll
-            for (int j = 0; j < NJMAX; ++j)
-              if ((okmask >> j) & 1u)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + bofs[j]), (lptr_t)(dst + j * 256), 4, 0, 0);
-            if (first_chunk) {
-#pragma unroll
-              for (int j = 0; j < NJMAX; ++j)
-                if (((wmask & ~okmask) >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
-            }
-          } else if (first_chunk || cg >= a.Cin) {
-            // a plane outside the clip (t) stays zero for the whole tile; a channel past Cin only exists in the last chunk
-#pragma unroll
-            for (int j = 0; j < NJMAX; ++j)
-              if ((wmask >> j) & 1u) xs[pl * PL + j * 256 + tid] = 0.f;
-          }
-        }
-      } else {
-#pragma unroll 2
-        for (int c = 0; c < CC; ++c) {
-          const int cg = ch * CC + c;
-          const bool cok = cg < a.Cin;
-          float sc = 1.f, sh = 0.f;
-          if (cok) {
-            sc = a.in_scale[cg];
-            sh = a.in_shift[cg];
-          }
-          float v[KT][NJMAX];
-#pragma unroll
-          for (int dt = 0; dt < KT; ++dt) {
-            const int tt = t + dt - (KT == 3 ? 1 : 0);
-            const bool tok = cok && tt >= 0 && tt < a.T;
-            const float* src = a.x + (((long)b * a.Cin + (cok ? cg : 0)) * a.T + (tok ? tt : 0)) * HW;
-#pragma unroll
-            for (int j = 0; j < NJMAX; ++j) {
-              const bool ld = tok && ((okmask >> j) & 1u);
-              v[dt][j] = ld ? src[gofs[j]] : 0.f;
-            }
-          }
-#pragma unroll
-          for (int dt = 0; dt < KT; ++dt) {
-            const int tt = t + dt - (KT == 3 ? 1 : 0);
-            const bool tok = cok && tt >= 0 && tt < a.T;
-#pragma unroll
-            for (int j = 0; j < NJMAX; ++j) {
-              if ((wmask >> j) & 1u) {
-                float val = v[dt][j];
-                if (tok && ((okmask >> j) & 1u)) {
-                  val = val * sc + sh;
-                  if (a.in_lrelu) val = hpvg_lrelu(val);
-                }
-                xs[(c * KT + dt) * PL + j * 256 + tid] = val;
-              }
-            }
-          }
-        }
-      }
+      // Retire every outstanding vector-memory write to a VGPR (the A prefetch issued past the previous chunk's last tap
+      // is never consumed) BEFORE the staging loop: the loop reuses those registers for addresses, and a write-after-
+      // write hazard the compiler cannot count across the loop's back edge costs an s_waitcnt vmcnt(0) per DMA, i.e.
+      // serialises all 72 loads of the chunk (measured: 1.98 -> 2.22 ms at stage 9).
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      conv_stage_chunk<CC, KT>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
       HPVG_PH(0)
       __syncthreads();
       HPVG_PH(1)
@@ -396,6 +419,154 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Narrow-output convolution (Cout <= 4): the tails 64->3 / 64->1 (networks_3d.py:175,341,362) and the backward-data
+// pass of the 3->64 heads.  With output channels as the GEMM's M these waste >= 90 % of every 32-row tile (1.07 ms at
+// stage 9).  Here the roles are swapped and the 9 in-plane taps move into N:
+//     P[pos][(o,dh,dw)] = sum_{c,dt} x[c][t+dt-pt][pos] * w[o][c][dt][dh][dw]          (GEMM: M = positions,
+//     y[o][h][w]        = bias[o] + sum_{dh,dw} P[(h+dh-1, w+dw-1)][(o,dh,dw)]           N = 9*Cout <= 36, K = Cin*KT)
+// Every input element is an A operand exactly once per tile (read straight from global, 128-byte segments, no LDS
+// staging and no tap replication); P of the tile + halo goes through LDS once and the shifted 9-term sum is the
+// epilogue.  84 % of the MFMA work is useful for Cout = 3 (27 of 32 columns).
+// Weights: wn[kstep][ntile][lane] = B fragment (k = (lane/32)*ksteps + kstep -> (c, dt); n = 32*ntile + lane%32 -> (o, dh, dw)).
+template <int KT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const ConvFwdArgs a, int ksteps, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) float P[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const long HW = (long)a.H * a.W;
+  const int RS = a.RS;
+  const int CO9 = a.Cout * 9;
+  const int pt = (KT == 3 ? 1 : 0);
+
+  const int tile = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const SkTile tc = sk_decode_tile(a, tile, 1);
+  const int b = tc.b, t = tc.t, h0 = tc.h0, w0 = tc.w0;
+  const int plload = (a.Th + 2) * RS;
+  const int nblk = (plload + 31) / 32;
+  const float* xb0 = a.x + (long)b * a.Cin * a.T * HW;
+
+  // K order: half-wave h of MFMA step s holds k = h*Kh + s (Kh = ksteps), i.e. channel h*Ch + s/KT (Cin even: Ch = Cin/2)
+  // and time tap s%KT: the (channel, plane) offset of a step is the same scalar for both halves and the lane part of
+  // the address is a per-block constant -> scalar-base + 32-bit lane offset loads, no per-load vector address math.
+  const int Kh = ksteps;
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int p = blk * 32 + l31;
+    const int hh = p / RS, ww = p - hh * RS;
+    const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+    const bool inimg = p < plload && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    const int kofs = half * Kh;                 // first k of this half-wave
+    const int c_h = kofs / KT, dt_h = kofs - c_h * KT;  // (channel, time tap) of k = kofs
+    // lane part of the address in bytes: (c_h, dt_h) plane + pixel (fits 32 bits: one sample is < 4 GB)
+    const unsigned lofs = (unsigned)((((long)c_h * a.T + dt_h) * HW + (inimg ? gh * a.W + gw : 0)) * 4);
+    const char* xbase = reinterpret_cast<const char*>(a.x + ((long)b * a.Cin * a.T + (t - pt)) * HW);
+    const float* wq = a.wp + lane;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    // K loop in chunks of KC steps, two register sets: the loads of chunk j+1 (inputs straight from global, weight
+    // fragments from L1/L2) are in flight while the MFMAs of chunk j issue
+    constexpr int KC = 16;
+    float ab[2][KC], bb[2][NT][KC];
+    auto load_chunk = [&](float (&av)[KC], float (&bv)[NT][KC], int s0) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int s = s0 + j;                    // uniform
+        const int cs = s / KT, ds = s - cs * KT; // uniform: channel / time-tap advance relative to (c_h, dt_h)
+        // k = kofs + s -> (c, dt) = (c_h, dt_h) advanced by s steps of the (c, dt) odometer
+        const int dtt = dt_h + ds;
+        const int c = c_h + cs + (dtt >= KT ? 1 : 0);
+        const int dt = dtt >= KT ? dtt - KT : dtt;
+        const int tt = t + dt - pt;
+        const bool ok = inimg && s < ksteps && c < a.Cin && tt >= 0 && tt < a.T;
+        // byte offset of (c, dt) relative to (c_h, dt_h): ((c - c_h)*T + (dt - dt_h)) * HW * 4
+        const long rel = (((long)(c - c_h) * a.T + (dt - dt_h)) * HW) * 4;
+        float v = ok ? *reinterpret_cast<const float*>(xbase + rel + lofs) : 0.f;
+        if (a.in_scale != nullptr && ok) {  // fused BatchNorm-apply (+ LeakyReLU) of the producer; padding stays zero
+          v = v * a.in_scale[c] + a.in_shift[c];
+          if (a.in_lrelu) v = hpvg_lrelu(v);
+        }
+        av[j] = v;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt][j] = s < ksteps ? wq[(s * NT + nt) * 64] : 0.f;
+      }
+    };
+    auto mma_chunk = [&](const float (&av)[KC], const float (&bv)[NT][KC]) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[nt][j], acc[nt], 0, 0, 0);
+    };
+    load_chunk(ab[0], bb[0], 0);
+    for (int s0 = 0; s0 < ksteps; s0 += 2 * KC) {
+      load_chunk(ab[1], bb[1], s0 + KC);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(ab[0], bb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(ab[0], bb[0], s0 + 2 * KC);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(ab[1], bb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D layout: column (n) = lane&31, row (position in the block) = (e&3) + 8*(e>>2) + 4*half
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 32 + l31;
+      if (n < CO9) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) P[n * pitch + blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = acc[nt][e];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: shifted 9-term sums, bias (after the accumulation), optional LeakyReLU, masked store
+  const int npos = a.Th * a.Tw;
+  for (int idx = tid; idx < npos; idx += 256) {
+    const int hh = idx / a.Tw, ww = idx - hh * a.Tw;
+    const int gh = h0 + hh, gw = w0 + ww;
+    if (gh >= a.H || gw >= a.W) continue;
+    const long sp = (long)t * HW + (long)gh * a.W + gw;
+    for (int o = 0; o < a.Cout; ++o) {
+      float v = 0.f;
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) v += P[(o * 9 + dh * 3 + dw) * pitch + (hh + dh) * RS + ww + dw];
+      if (a.bias) v += a.bias[o];
+      if (a.out_lrelu) v = hpvg_lrelu(v);
+      a.y[((long)b * a.Cout + o) * a.T * HW + sp] = v;
+    }
+  }
+}
+
+// B fragments of the narrow kernel; transpose_flip as in conv_pack_kernel
+__global__ void conv_pack_narrow_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, float* __restrict__ wn,
+                                        int Cin_k, int Cout_k, int KT, int NT, int ksteps, int transpose_flip, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  long r = idx >> 6;
+  const int nt = r % NT;
+  const int s = (int)(r / NT);
+  const int k = (lane >> 5) * ksteps + s;  // half-wave h holds k = h*ksteps + s (see conv_narrow_kernel)
+  const int n = nt * 32 + (lane & 31);
+  const int c = k / KT, dt = k - c * KT;
+  const int o = n / 9, tap = dt * 9 + (n - o * 9);
+  const int taps = KT * 9;
+  float val = 0.f;
+  if (o < Cout_k && c < Cin_k) {
+    if (!transpose_flip) val = w[((long)o * Cin_k + c) * taps + tap];
+    else val = w[((long)c * Cout_k + o) * taps + (taps - 1 - tap)];
+    if (inv_scale) val *= inv_scale[0];
+  }
+  wn[idx] = val;
+}
+
+// ------------------------------------------------------------------------------------------
 // weight pack: natural [Cout][Cin][taps] -> MFMA A-fragment order
 //   wp[chunk][tap][mblock][lane][cp] = Wsrc[o = mblock*32 + (lane&31)][c = chunk*CC + 2cp + (lane>>5)][tap]
 // transpose_flip=1 packs the backward-data weights (Wsrc[o'][c'][tap] = W[c'][o'][ntaps-1-tap]).
@@ -442,7 +613,7 @@ constexpr long CONV_SLOTS = 2L * HPVG_NUM_CU;  // co-resident workgroups: two pe
 // pipe, half that when alone) + ~8 us of staging / barrier work the co-resident workgroup does not hide + the input
 // planes it stages; tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block,
 // written by the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth).
-Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
+Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk, bool narrow) {
   const int CC = conv_cc(Cin);
   const int nchunk = hpvg_cdiv(Cin, CC);
   const int mbtot = hpvg_cdiv(Cout, 32);
@@ -452,7 +623,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
   static const int only_nb = [] { const char* e = getenv("HPVG_PLAN_NB"); return e ? atoi(e) : 0; }();
   static const int only_mb = [] { const char* e = getenv("HPVG_PLAN_MB"); return e ? atoi(e) : 0; }();
   for (int MB = (mbtot >= 2 ? 2 : 1); MB >= 1; --MB) {
-    if (only_mb && MB != only_mb && mbtot >= 2) continue;
+    if (only_mb && MB != only_mb && mbtot >= 2 && !narrow) continue;
     const int gridy = hpvg_cdiv(mbtot, MB);
     for (int Tw = 1; Tw <= W; ++Tw) {
       const int ntw = hpvg_cdiv(W, Tw);
@@ -476,7 +647,15 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
         const long ntl = (long)B * T * nth * ntw * gridy;
         const double stage_us = 0.0065 * (Th + 2) * RS;
         double cost;
-        if (streamk) {
+        if (narrow) {
+          // GEMM over the tile + halo positions, one workgroup per tile: blocks of 32 positions over 4 waves, K steps of
+          // 64 cycles each, ~3 us of epilogue; the P image (9*Cout rows) must leave room for two workgroups per CU
+          const int nblk_h = hpvg_cdiv((Th + 2) * RS, 32);
+          if ((size_t)(9 * Cout) * ((size_t)nblk_h * 32 + 1) * sizeof(float) > 38 * 1024) continue;  // >= 4 workgroups per CU hide the load latency
+          const double per_tile = hpvg_cdiv(nblk_h, 4) * (double)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 0.033 + 3.0;
+          const double waves = ntl <= CONV_SLOTS ? 1.0 : (double)ntl / (double)CONV_SLOTS;
+          cost = waves * per_tile + 1e-3 * (double)ntl;
+        } else if (streamk) {
           const long items_tot = ntl * nchunk;
           const long S = items_tot < CONV_SLOTS ? items_tot : CONV_SLOTS;
           const long ndp = ntl / S;
@@ -509,7 +688,11 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
 }
 
 // The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).
+inline bool conv_is_narrow(int Cin, int Cout) { return Cout <= 4 && Cin > 4; }
+
 Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
+  const bool narrow = conv_is_narrow(Cin, Cout);
+  if (narrow) streamk = false;
   struct Key { int B, Cin, Cout, T, H, W, KT, sk; };
   struct Entry { Key k; Plan p; };
   static thread_local Entry cache[128];
@@ -520,7 +703,7 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool strea
     if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.sk == k.sk)
       return cache[i].p;
   }
-  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk);
+  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
   if (used < 128) cache[used++] = Entry{k, p};
   return p;
 }
@@ -565,6 +748,27 @@ int dispatch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   }
 }
 
+template <int KT>
+int launch_conv_narrow(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
+  const int ksteps = hpvg_cdiv(a.Cin * KT, 2);
+  const int pitch = (hpvg_cdiv((p.Th + 2) * p.RS, 32) * 32) | 1;  // odd: the 32 columns of a block land in 32 banks
+  const size_t lds = (size_t)(9 * a.Cout) * pitch * sizeof(float);
+#define HPVG_NARROW(NT)                                                                                              \
+  {                                                                                                                  \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_narrow_kernel<KT, NT>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                 \
+        (void)hipGetLastError();                                                                                     \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((conv_narrow_kernel<KT, NT>), dim3(a.ntl), dim3(256), lds, s, a, ksteps, pitch);              \
+  }
+  if (9 * a.Cout <= 32) HPVG_NARROW(1) else HPVG_NARROW(2)
+#undef HPVG_NARROW
+  return hpvg_launch_status();
+}
+
 // stream-K grid for a plan: all co-resident slots, or one workgroup per item when there are fewer items than slots
 inline int conv_sk_grid(int ntl, int nchunk) {
   const long items = (long)ntl * nchunk;
@@ -578,6 +782,7 @@ extern "C" {
 
 // number of floats of the packed-weight buffer for a conv with Cin -> Cout (kernel view)
 size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) {
+  if (conv_is_narrow(Cin, Cout)) return (size_t)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 64;  // wn[kstep][ntile][lane]
   const int CC = conv_cc(Cin);
   const int nchunk = hpvg_cdiv(Cin, CC);
   const int mbtot = hpvg_cdiv(Cout, 32);
@@ -593,6 +798,12 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
   if (!w || !wp || (KT != 1 && KT != 3) || Cin_layer < 1 || Cout_layer < 1) return HPVG_ERR_ARG;
   const int Cin_k = transpose_flip ? Cout_layer : Cin_layer;
   const int Cout_k = transpose_flip ? Cin_layer : Cout_layer;
+  if (conv_is_narrow(Cin_k, Cout_k)) {
+    const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
+    hipLaunchKernelGGL(conv_pack_narrow_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
+                       Cin_k, Cout_k, KT, hpvg_cdiv(9 * Cout_k, 32), hpvg_cdiv(Cin_k * KT, 2), transpose_flip, total);
+    return hpvg_launch_status();
+  }
   const int CC = conv_cc(Cin_k);
   const int nchunk = hpvg_cdiv(Cin_k, CC);
   const int mbtot = hpvg_cdiv(Cout_k, 32);
@@ -618,7 +829,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   static const bool sk_off = [] { const char* e = getenv("HPVG_CONV_SK"); return e && atoi(e) == 0; }();
   const int CC = conv_cc(Cin);
   const int nchunk = hpvg_cdiv(Cin, CC);
-  bool streamk = !sk_off && ws != nullptr;
+  bool streamk = !sk_off && ws != nullptr && !conv_is_narrow(Cin, Cout);
   Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk);
   if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
   int ntl = B * T * p.nth * p.ntw * p.gridy;
@@ -637,6 +848,10 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   a.in_lrelu = in_lrelu; a.out_lrelu = out_lrelu;
   a.gridy = p.gridy;
   a.ntl = ntl;
+  if (conv_is_narrow(Cin, Cout)) {
+    a.ndp = 1; a.skbase = ntl; a.skpart = nullptr;
+    return KT == 3 ? launch_conv_narrow<3>(a, p, (hipStream_t)stream) : launch_conv_narrow<1>(a, p, (hipStream_t)stream);
+  }
   const int S = streamk ? conv_sk_grid(ntl, nchunk) : ntl;  // S = ntl: one data-parallel round, no stream-K part
   a.ndp = ntl / S;
   a.skbase = a.ndp * S;
@@ -649,6 +864,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
 // scratch the stream-K schedule of hpvg_conv_fwd_f32 wants for this shape
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
+  if (conv_is_narrow(Cin, Cout)) return 0;
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
   if (p.Th == 0) return 0;
   return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nth * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin))));
