@@ -27,7 +27,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
 # collected separately and committed as profiles/r01_pmc_traffic_stage9.csv; bench.py cannot run the profiler itself.
-MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.095e9}
+MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.219e9}  # conv_mfma_kernel 1.181e9 + conv_fixup_kernel 3.8e7
 
 
 CONFIG = "video"  # set by --config: "video" = BASELINE configs[2] (metric config), "image" = configs[1] (2-D path)
@@ -298,7 +298,7 @@ def main():
             B, C, T, H, W = key
             flops = 2.0 * B * 64 * 64 * (27 if CONFIG == "video" else 9) * T * H * W
             achieved = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<8,3,2,4> + conv_fixup_kernel (64->64 3x3x3 fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)",
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)" % ("3x3x3" if CONFIG == "video" else "3x3"),
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": MEASURED_TRAFFIC_BYTES.get(tuple(key)),
                     "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 27, "shape": list(key),

@@ -1,0 +1,26 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (separate passes) into per-kernel averages.
+usage: python tools/pmc_summary.py <fetch_csv> <write_csv> > profiles/xxx.csv
+gfx950 correction (MI355X_MICROARCH.md, HBM section; calibrated here on channel_sum_partial_kernel, which reads each
+input byte exactly once): FETCH_SIZE counts 128-byte requests as 64 -> fetch_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact."""
+import csv, sys, collections, re
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        name = name.split("(")[0][-60:] if name.startswith("void at::") else name.split("(")[0]
+        key = (name, r["Grid_Size"])
+        acc[key][0] += float(r["Counter_Value"])
+        acc[key][1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+f = load(sys.argv[1], "FETCH_SIZE")
+w = load(sys.argv[2], "WRITE_SIZE")
+print("kernel,grid,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected")
+for k in sorted(set(f) | set(w)):
+    fk, wk = f.get(k, 0.0), w.get(k, 0.0)
+    print("%s,%s,%.4g,%.4g,%.4g" % (k[0].replace(",", ";"), k[1], fk, wk, 2 * fk * 1024 + wk * 1024))
