@@ -101,6 +101,13 @@ int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, fl
 int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
                                     void* stream);
 
+/* ---- data front-end (the step before the path): frames [N][H][W][3] uint8 RGB -> the stage's clip tensor
+ * [3][count][h][w] fp32: cv2.resize(INTER_LINEAR) geometry per frame (datasets/generate_frames.py:44-46), temporal window
+ * frame[first + k*step] (datasets/video.py:56-57), /255, K.hflip, K.normalize(0.5, 0.5), permute C,T,H,W (video.py:58-82).
+ * quantize != 0 rounds the resized value to a uint8 level first, as cv2.resize on uint8 does. */
+int hpvg_frames_resize_norm_u8_f32(const unsigned char* src, float* dst, int N, int H, int W, int first, int step, int count, int h,
+                                   int w, int hflip, int quantize, void* stream);
+
 /* ---- spectral norm (nn.utils.spectral_norm, networks_3d.py:63): one power iteration, sigma, 1/sigma; backward through sigma */
 int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, int Co, int K, int do_iter,
                            float eps, void* ws, size_t ws_bytes, void* stream);
