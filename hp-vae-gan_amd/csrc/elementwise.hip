@@ -123,6 +123,19 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nsplit, 
   }
 }
 
+// sums[c][j] = sum_k part[c][k][j]: the rank-local per-channel pair handed to the all-reduce of a batch-split BatchNorm
+__global__ void bn_sum_partials_kernel(const double* __restrict__ part, int nsplit, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += part[((long)c * nsplit + k) * 2 + 0];
+    s2 += part[((long)c * nsplit + k) * 2 + 1];
+  }
+  sums[2 * c] = s1;
+  sums[2 * c + 1] = s2;
+}
+
 // y = lrelu?(scale[c]*x + shift[c])      grid (blocks over S, B*C)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ y, int C, long S,
@@ -555,6 +568,51 @@ int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* bet
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)B * (double)S,
                      eps, momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+  return hpvg_launch_status();
+}
+
+// ---- BatchNorm with the batch split over ranks (multi-GPU): rank-local sums -> caller all-reduces -> finalize / apply
+// sums[c] = (sum x, sum x^2) over this rank's part of the batch, double
+int hpvg_bn_sums_f32(const float* x, double* sums, void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!x || !sums || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, sums);
+  return hpvg_launch_status();
+}
+// statistics from (all-reduced) sums over `count` elements per channel; same outputs as hpvg_bn_train_stats_f32
+int hpvg_bn_finalize_f32(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                         int C, void* stream) {
+  if (!sums || !mean || !invstd || !scale || !shift || C < 1 || !(count >= 1.0)) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, 1, C, count, eps, momentum,
+                     gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+  return hpvg_launch_status();
+}
+// sums[c] = (sum dz, sum dz*xhat) over this rank's part of the batch (dz = dh * LeakyReLU'(z)), double
+int hpvg_bn_act_bwd_sums_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                             const float* shift, int lrelu, double* sums, void* ws, size_t ws_bytes, int B, int C, long S,
+                             void* stream) {
+  if (!dh || !r || !mean || !invstd || !scale || !shift || !sums || !ws) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns,
+                     lrelu, (double*)ws);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, sums);
+  return hpvg_launch_status();
+}
+// dr from the GLOBAL sums (float pairs) and 1/(global element count per channel)
+int hpvg_bn_act_bwd_apply_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, int lrelu, const float* sums, float inv_count, float* dr, int B, int C, long S,
+                              void* stream) {
+  if (!dh || !r || !mean || !invstd || !scale || !shift || !sums || !dr || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  int nbx = hpvg_cdiv(S, 256 * 4);
+  if (nbx > 1024) nbx = 1024;
+  hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, (hipStream_t)stream, dh, r, mean, invstd, scale,
+                     shift, sums, dr, C, S, inv_count, lrelu);
   return hpvg_launch_status();
 }
 

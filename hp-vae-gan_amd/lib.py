@@ -41,6 +41,10 @@ _SIGS = {
     "hpvg_bn_train_stats_f32": [P, P, P, P, P, F, F, P, P, P, P, P, Z, I, I, L, P],
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
     "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, P, P, P, P, Z, I, I, L, P],
+    "hpvg_bn_sums_f32": [P, P, P, Z, I, I, L, P],
+    "hpvg_bn_finalize_f32": [P, D, P, P, P, P, F, F, P, P, P, P, I, P],
+    "hpvg_bn_act_bwd_sums_f32": [P, P, P, P, P, P, I, P, P, Z, I, I, L, P],
+    "hpvg_bn_act_bwd_apply_f32": [P, P, P, P, P, P, I, P, F, P, I, I, L, P],
     "hpvg_lrelu_mask_mul_f32": [P, P, P, L, P],
     "hpvg_add_f32": [P, P, P, L, P],
     "hpvg_tanh_fwd_f32": [P, P, P, L, P],

@@ -92,9 +92,16 @@ class BatchNorm(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
+    # multi-GPU: (allreduce callable, number of ranks) when the batch is split over a process group (multigpu.py sets
+    # it on every BatchNorm of a generator whose passes are sharded by sample); None = the whole batch is local
+    sync = None
+
     def forward(self, r, lrelu=True):
         if self.training:
             self.num_batches_tracked.add_(1)
+            if self.sync is not None:
+                return ops.BNActSync.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
+                                           self.eps, lrelu, self.sync[0], self.sync[1])
             return ops.BNAct.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
                                    lrelu)
         with torch.no_grad():

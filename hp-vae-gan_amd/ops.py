@@ -283,6 +283,55 @@ class BNAct(Function):
         return dr, dgb[0], dgb[1], None, None, None, None, None
 
 
+class BNActSync(Function):
+    """BNAct with the batch split over the ranks of a process group (multi-GPU, one process per GPU): each rank reduces
+    its own samples, `allreduce(t)` (a callable summing a float64 tensor over the group, in place) combines the
+    per-channel pairs, and statistics / running buffers / dr follow from the global sums - the same arithmetic as BNAct
+    over the whole batch.  dgamma / dbeta are this rank's share (the parameter all-reduce adds the shares up)."""
+
+    @staticmethod
+    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu, allreduce, nranks):
+        r = _c(r)
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        ws = workspace(call("hpvg_bn_ws_bytes", C), dev)
+        sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
+        call("hpvg_bn_sums_f32", ptr(r), ptr(sums), ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
+        allreduce(sums)
+        count = float(B) * float(S) * float(nranks)
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        call("hpvg_bn_finalize_f32", ptr(sums), ctypes.c_double(count), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), C, stream())
+        h = torch.empty_like(r)
+        call("hpvg_affine_act_f32", ptr(r), ptr(stats[2]), ptr(stats[3]), ptr(h), 1 if lrelu else 0, B, C, ctypes.c_long(S),
+             stream())
+        ctx.save_for_backward(r, stats)
+        ctx.lrelu, ctx.allreduce, ctx.count = lrelu, allreduce, count
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        r, stats = ctx.saved_tensors
+        dh = _c(dh)
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        ws = workspace(call("hpvg_bn_ws_bytes", C), dev)
+        local = torch.empty(C, 2, dtype=torch.float64, device=dev)  # (sum dz, sum dz*xhat) of this rank's samples
+        call("hpvg_bn_act_bwd_sums_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             1 if ctx.lrelu else 0, ptr(local), ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
+        glob = local.clone()
+        ctx.allreduce(glob)
+        gsum = glob.to(torch.float32).contiguous()
+        dr = torch.empty_like(r)
+        call("hpvg_bn_act_bwd_apply_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             1 if ctx.lrelu else 0, ptr(gsum), float(1.0 / ctx.count), ptr(dr), B, C, ctypes.c_long(S), stream())
+        loc32 = local.to(torch.float32)
+        return dr, loc32[:, 1].contiguous(), loc32[:, 0].contiguous(), None, None, None, None, None, None, None
+
+
 class AffineAct(Function):
     """y = LeakyReLU_opt(scale[c]*x + shift[c]) - eval-mode BatchNorm apply (running statistics)."""
 

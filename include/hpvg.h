@@ -68,6 +68,19 @@ int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, 
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
                         const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B,
                         int C, long S, void* stream);
+/* BatchNorm with the batch split over ranks (one process per GPU): the rank-local per-channel sums are double pairs the
+ * caller all-reduces (RCCL) between the two halves; statistics, running buffers and dr then follow from the global sums.
+ * Same arithmetic as the single-GPU entry points above (which are sums + finalize / sums + apply in one call). */
+int hpvg_bn_sums_f32(const float* x, double* sums, void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
+int hpvg_bn_finalize_f32(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                         int C, void* stream);
+int hpvg_bn_act_bwd_sums_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                             const float* shift, int lrelu, double* sums, void* ws, size_t ws_bytes, int B, int C, long S,
+                             void* stream);
+int hpvg_bn_act_bwd_apply_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, int lrelu, const float* sums, float inv_count, float* dr, int B, int C, long S,
+                              void* stream);
 /* out = dy * (h > 0 ? 1 : 0.2): leaky_relu_backward on the in-place activated tensor (networks_3d.py:21) */
 int hpvg_lrelu_mask_mul_f32(const float* dy, const float* h, float* out, long n, void* stream);
 

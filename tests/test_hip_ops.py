@@ -145,6 +145,62 @@ def test_bn_act(ops, shape):
     assert_close(dbd, db, RTOL, "bn.dbeta")
 
 
+def test_bn_act_batch_split_equals_whole_batch(ops):
+    """Multi-GPU BatchNorm: two 'ranks' hold one sample each; with the per-channel sums exchanged (here: added by hand, as
+    the all-reduce would) outputs, running statistics, dr and the summed parameter gradients equal BNAct on the batch."""
+    B, C, sp = 2, 24, (3, 7, 9)
+    r = _rand(B, C, *sp, seed=31).to(DEV)
+    dh = _rand(B, C, *sp, seed=32).to(DEV)
+    gamma = (_rand(C, seed=33) * 0.2 + 1).to(DEV)
+    beta = (_rand(C, seed=34) * 0.1).to(DEV)
+    rm0, rv0 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    g1, b1 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    h = ops.BNAct.apply(r1, g1, b1, rm, rv, 0.1, 1e-5, True)
+    dr, dg, db = torch.autograd.grad(h, [r1, g1, b1], dh)
+
+    # two ranks executed one after the other.  The "all-reduce" adds the partner's rank-local tensor: the forward pair
+    # comes from the raw entry point, the backward pair from a first run of the partner (it only depends on the partner's
+    # samples and on the global statistics, which are already right in that run).
+    import ctypes
+    from hp_vae_gan_amd import lib as hplib
+    S = sp[0] * sp[1] * sp[2]
+    fwd_local = {}
+    for rank in (0, 1):
+        x = r[rank:rank + 1].contiguous()
+        ws = ops.workspace(hplib.call("hpvg_bn_ws_bytes", C), x.device)
+        sums = torch.empty(C, 2, dtype=torch.float64, device=DEV)
+        hplib.call("hpvg_bn_sums_f32", hplib.ptr(x), hplib.ptr(sums), hplib.ptr(ws), ctypes.c_size_t(ws.numel()), 1, C,
+                   ctypes.c_long(S), hplib.stream())
+        fwd_local[rank] = sums
+
+    def run(rank, partner_bwd):
+        calls = []
+
+        def allreduce(t):
+            calls.append(t.clone())
+            t.add_(fwd_local[1 - rank] if len(calls) == 1 else partner_bwd)
+
+        g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        r2 = r[rank:rank + 1].clone().requires_grad_(True)
+        rm2, rv2 = rm0.clone(), rv0.clone()
+        h2 = ops.BNActSync.apply(r2, g2, b2, rm2, rv2, 0.1, 1e-5, True, allreduce, 2)
+        grads = torch.autograd.grad(h2, [r2, g2, b2], dh[rank:rank + 1])
+        return (h2, rm2, rv2) + grads, calls[1]
+
+    bwd_local = {rank: run(rank, torch.zeros(C, 2, dtype=torch.float64, device=DEV))[1] for rank in (0, 1)}
+    outs = {rank: run(rank, bwd_local[1 - rank])[0] for rank in (0, 1)}
+    for rank in (0, 1):
+        h2, rm2, rv2, dr2, dg2, db2 = outs[rank]
+        assert_close(h2, h[rank:rank + 1], 1e-6, "syncbn.h")
+        assert_close(rm2, rm, 1e-6, "syncbn.running_mean")
+        assert_close(rv2, rv, 1e-6, "syncbn.running_var")
+        assert_close(dr2, dr[rank:rank + 1], 1e-5, "syncbn.dr")
+    assert_close(outs[0][4] + outs[1][4], dg, 1e-5, "syncbn.dgamma (sum of shares)")
+    assert_close(outs[0][5] + outs[1][5], db, 1e-5, "syncbn.dbeta (sum of shares)")
+
+
 @pytest.mark.parametrize("Co,Ci,nd", [(64, 3, 3), (64, 64, 3), (24, 16, 3), (64, 64, 2), (1, 64, 3)])
 def test_spectral_norm_weight(ops, Co, Ci, nd):
     w = _rand(Co, Ci, *([3] * nd), seed=30, scale=0.1).requires_grad_(True)
