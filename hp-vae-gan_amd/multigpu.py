@@ -25,8 +25,18 @@ BatchNorm running statistics / SN u,v of the generator are advanced only by the 
 influence training: the reference keeps netG in train mode for every forward); `sync_buffers()` averages them at the
 end of a stage.
 
+Four ranks ("quad" mode, late stages): the generator passes are ALSO split over the batch - rank q = 2*pass + sample,
+rec pass on ranks {0, 1}, rand pass on ranks {2, 3}, each on its own sample - with BatchNorm statistics exchanged inside
+each pass pair (ops.BNActSync: a 2 x C double all-reduce per BatchNorm forward and backward, the only new traffic).
+Rank (1, b) makes fake[b], keeps the gradient-penalty and the G-step critic work of sample b, and ships fake[b] once to
+rank (0, b), which evaluates D(real[b]) and D(fake[b]).  No gradient crosses ranks except inside the all-reduces.
+Per-rank work at the finest stage drops from ~36 to ~19.5 conv-units of 72 (SURVEY 8e numbers), i.e. <= 3.7x over one
+GPU; early stages (launch / latency bound) stay on two ranks.  Ranks >= 4 idle (spatial decomposition is the next step).
+
 The arithmetic is delegated to a `backend` (HipBackend below: the gfx950 kernels; the gloo tests plug in a torch-CPU
 backend built on the oracle) so that the distributed logic is testable without a GPU."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -117,20 +127,58 @@ class HipBackend:
         from . import utils
         return utils.generate_noise(ref=ref)
 
+    def advance_sn(self, net, n):
+        """Run n spectral-norm power iterations on every SN conv of `net` without using the weight: keeps the u/v
+        buffers in step with the single-GPU sequence of D forwards when a rank skips some of them."""
+        from .modules._nets import SNConv
+        with torch.no_grad():
+            for _ in range(n):
+                for m in net.modules():
+                    if isinstance(m, SNConv) and m.training:
+                        m.effective_weight()
+
+    def set_sync_bn(self, netG, sync):
+        """sync = (allreduce callable, ranks) or None: batch-split BatchNorm on every BatchNorm of the generator."""
+        from .modules._nets import BatchNorm
+        for m in netG.modules():
+            if isinstance(m, BatchNorm):
+                m.sync = sync
+
+
+_GROUPS = {}
+
+
+def subgroup(ranks):
+    """Process group of `ranks` (None = the whole world), created once per process and reused by every stage trainer.
+    dist.new_group is collective: every rank calls this with the same lists in the same order."""
+    ranks = tuple(ranks)
+    if len(ranks) == dist.get_world_size():
+        return None
+    if ranks not in _GROUPS:
+        _GROUPS[ranks] = dist.new_group(ranks=list(ranks))
+    return _GROUPS[ranks]
+
 
 class DistStageTrainer:
-    """One pyramid stage on `world` ranks (see module docstring).  Mirrors train.StageTrainer.step()."""
+    """One pyramid stage on `world` ranks (see module docstring).  Mirrors train.StageTrainer.step().
+    quad=True (needs world >= 4): generator passes and discriminator work over four ranks."""
 
-    def __init__(self, opt, netG, netD, backend, g_groups, group=None):
+    def __init__(self, opt, netG, netD, backend, g_groups, group=None, quad=False):
         self.opt, self.netG, self.netD, self.be = opt, netG, netD, backend
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
         self.is_gan = opt.vae_levels < opt.scale_idx + 1
         if self.is_gan and opt.batch_size != 2:
             raise NotImplementedError("the batch split of the discriminator work assumes batch_size == 2 (reference default)")
-        self.active = self.rank < 2 or not self.is_gan     # GAN stages: two working ranks
-        # collectives of a GAN stage run over the two working ranks only
-        self.pair = dist.new_group(ranks=[0, 1]) if self.world > 2 else None
+        self.quad = bool(quad) and self.is_gan and self.world >= 4
+        nwork = 4 if self.quad else 2
+        self.active = self.rank < nwork or not self.is_gan     # GAN stages: two (four) working ranks
+        # collectives of a GAN stage run over the working ranks only (every rank creates every group, in this order)
+        self.pair = subgroup([0, 1]) if self.world > 2 else None
+        if self.world >= 4:
+            self.g_rand = subgroup([2, 3])
+            self.g_quad = subgroup([0, 1, 2, 3])
+        self.work = (self.g_quad if self.quad else self.pair) if self.world >= 4 else self.pair
         self.o = backend.optimizers(netG, netD if self.is_gan else None, g_groups, opt.lr_d, opt.beta1)
         self.iteration = 0
         self.dev = next(netG.parameters()).device
@@ -163,6 +211,10 @@ class DistStageTrainer:
                 amp = opt.noise_amp_init * float(torch.sqrt(self.be.mse(real, rec)).item()) / opt.batch_size
         if self.is_gan:
             amp = self._bcast_float(amp, 0)
+            if self.quad and self.rank == 1:
+                # rank 0's calibration forward advanced the encoder's spectral-norm u/v by one power iteration; the other
+                # rank of the rec pass must use the same sigma
+                self.be.advance_sn(self.netG, 1)
         opt.noise_amp = amp
         opt.Noise_Amps[-1] = amp
 
@@ -176,6 +228,8 @@ class DistStageTrainer:
         self.iteration += 1
         if not self.active:
             return {}
+        if self.quad:
+            return self._quad_step(real, real_zero, noise_init, alpha)
         r, g = self.rank, self.pair
         netG, netD, be, o = self.netG, self.netD, self.be, self.o
         out = {}
@@ -228,6 +282,78 @@ class DistStageTrainer:
         out.update(errD_real=stats[0], errD_fake=stats[1], gradient_penalty=stats[2], errG=stats[3])
         return out
 
+    def _quad_step(self, real, real_zero, noise_init, alpha):
+        """GAN-stage iteration on four ranks: rank q = 2*p + b runs pass p (0 rec, 1 rand) on batch sample b."""
+        opt, netG, netD, be, o = self.opt, self.netG, self.netD, self.be, self.o
+        p, b = divmod(self.rank, 2)
+        g_pass = self.pair if p == 0 else self.g_rand
+        g_all = self.g_quad
+        out = {}
+        # batch-split BatchNorm inside the pass pair; every noise tensor is drawn for the whole batch (identical generator
+        # state on the two ranks of a pass) and this rank keeps its sample
+        be.set_sync_bn(netG, (lambda t: all_reduce(t, group=g_pass), 2))
+        prev_src = netG.noise_source
+        draw = prev_src if prev_src is not None else be.noise
+
+        def sliced(ref):
+            full = draw(torch.empty((opt.batch_size,) + tuple(ref.shape[1:]), device=ref.device))
+            return full[b:b + 1].contiguous()
+        netG.noise_source = sliced
+        try:
+            real_b = real[b:b + 1].contiguous()
+            if alpha is None:
+                alpha = torch.rand(1, 1) if self.rank == 0 else torch.zeros(1, 1)
+            a = alpha.reshape(1).to(self.dev, torch.float32).clone()
+            broadcast(a, src=0, group=g_all)
+            o.zero_D()
+            zero = torch.zeros((), device=self.dev)
+            errD_real = errD_fake = gp = errG_b = rec_loss = zero
+            if p == 0:
+                generated, _, _ = netG(real_zero[b:b + 1].contiguous(), opt.Noise_Amps, mode="rec")
+                fake_b = torch.empty_like(real_b)
+                recv(fake_b, src=2 + b)
+                errD_real = be.wgan_mean(netD(real_b), -1.0) * 0.5   # D forward 1 of the reference sequence
+                errD_fake = be.wgan_mean(netD(fake_b), 1.0) * 0.5    # D forward 2
+                (errD_real + errD_fake).backward()
+                be.advance_sn(netD, 1)                               # forward 3 (gradient penalty) runs on the rand ranks
+            else:
+                if noise_init is None:
+                    noise_init = be.noise(torch.empty(opt.Z_init_size, device=self.dev))
+                z = noise_init[b:b + 1].contiguous()
+                fake, _ = netG(z, opt.Noise_Amps, noise_init=z, mode="rand")
+                fake_b = fake.detach().contiguous()
+                send(fake_b, dst=b)
+                be.advance_sn(netD, 2)                               # forwards 1 and 2 run on the rec ranks
+                gp = be.grad_penalty(netD, real_b, fake_b, opt.lambda_grad, a) * 0.5   # D forward 3
+                gp.backward()
+            o.allreduce_D(g_all)
+            o.step_D()
+            # -- G step: the critic term of sample b stays on the rank that made fake[b]; the rec ranks take the MSE term
+            o.zero_G()
+            if p == 1:
+                leaf = fake_b.detach().requires_grad_(True)
+                for q in netD.parameters():
+                    q.requires_grad_(False)
+                errG_b = be.wgan_mean(netD(leaf), -1.0) * (0.5 * opt.disc_loss_weight)
+                (dfake_b,) = torch.autograd.grad(errG_b, leaf)
+                for q in netD.parameters():
+                    q.requires_grad_(True)
+                fake.backward(dfake_b)
+            else:
+                be.advance_sn(netD, 1)                               # forward 4 (critic term of the G step), new weights
+                rec_loss = be.mse(generated, real_b) * 0.5
+                (opt.rec_weight * rec_loss).backward()
+            o.allreduce_G(g_all)
+            o.clip_step_G(opt.grad_clip)
+            stats = torch.stack([errD_real.detach(), errD_fake.detach(), gp.detach(), errG_b.detach(), rec_loss.detach()])
+            stats = stats.reshape(5).to(torch.float32).clone()
+            all_reduce(stats, group=g_all)
+            out.update(errD_real=stats[0], errD_fake=stats[1], gradient_penalty=stats[2], errG=stats[3], rec_loss=stats[4])
+        finally:
+            netG.noise_source = prev_src
+            be.set_sync_bn(netG, None)
+        return out
+
     def _vae_step(self, real, real_zero):
         """Single generator pass with BatchNorm over the batch: every rank runs the identical step."""
         opt, netG, be, o = self.opt, self.netG, self.be, self.o
@@ -250,12 +376,12 @@ class DistStageTrainer:
 
     def sync_buffers(self):
         """Average the generator's buffers (BN running stats, SN u/v) over the working ranks at the end of a stage."""
-        n = 2 if (self.is_gan and self.world >= 2) else 1
+        n = (4 if self.quad else 2) if (self.is_gan and self.world >= 2) else 1
         if n == 1 or not self.active:
             return
         for b in self.netG.buffers():
             if b.dtype.is_floating_point:
-                all_reduce(b, group=self.pair)
+                all_reduce(b, group=self.work)
                 b.div_(n)
 
 
@@ -293,7 +419,10 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
         real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
         opt.Z_init_size = [opt.batch_size, opt.latent_dim, *shapes[0]]
-        trainer = DistStageTrainer(opt, netG, netD, HipBackend(opt), hp_train.generator_param_groups(opt, netG))
+        # four working ranks from the first stage whose iteration is long enough to pay for the BatchNorm exchanges
+        # (~130 small all-reduces per iteration); earlier GAN stages run on two ranks
+        quad = world >= 4 and s >= int(os.environ.get("HPVG_QUAD_MIN_STAGE", "5"))
+        trainer = DistStageTrainer(opt, netG, netD, HipBackend(opt), hp_train.generator_param_groups(opt, netG), quad=quad)
         built.append((s, trainer, real, real_zero))
 
     class Runner:

@@ -1,5 +1,5 @@
-"""GPU rehearsal of the N>1 path with the real kernels: two processes share the box's single MI355X (gloo rendezvous,
-messages staged through the host) and run hp_vae_gan_amd.multigpu.DistStageTrainer with the HIP backend on a golden
+"""GPU rehearsal of the N>1 path with the real kernels: two (four, in quad mode) processes share the box's single MI355X
+(gloo rendezvous, messages staged through the host) and run hp_vae_gan_amd.multigpu.DistStageTrainer with the HIP backend on a golden
 GAN-stage fixture; both replicas must land on the reference's post-step parameters."""
 import os
 import socket
@@ -27,7 +27,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, fname, outdir):
+def _worker(rank, world, port, fname, outdir, quad=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -51,9 +51,12 @@ def _worker(rank, world, port, fname, outdir):
     opt.Noise_Amps = list(fx["noise_amps_init"])
     rec = fx["iters"][0]
     opt.Z_init_size = list(rec["noise_init"].shape)
-    tr = multigpu.DistStageTrainer(opt, netG, netD, multigpu.HipBackend(opt), hp_train.generator_param_groups(opt, netG))
+    tr = multigpu.DistStageTrainer(opt, netG, netD, multigpu.HipBackend(opt), hp_train.generator_param_groups(opt, netG), quad=quad)
     noises = rec["noises"]
-    netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], dev)
+    if quad:  # rank 0: calibration eps + rec eps, rank 1: rec eps, rand ranks {2, 3}: the level noises
+        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else (noises[1:2] if rank == 1 else noises[2:]), dev)
+    else:
+        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], dev)
     out = tr.step(fx["real"].to(dev), fx["real_zero"].to(dev), noise_init=rec["noise_init"].to(dev), alpha=rec["alpha"])
     torch.cuda.synchronize()
     torch.save({"out": {k: v.cpu() for k, v in out.items()}, "amps": opt.Noise_Amps,
@@ -87,3 +90,32 @@ def test_two_rank_hip_step_matches_reference(fname):
     for k, v in got[0]["G"].items():
         if O.is_param(k):
             assert torch.equal(v, got[1]["G"][k]), "replicas diverged: " + k
+
+
+@pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step2d_gan_s2.pt"])
+def test_four_rank_hip_step_matches_reference(fname):
+    """Quad mode with the real kernels (ops.BNActSync inside the pass pairs, spectral-norm replay): every replica lands on
+    the reference's post-step parameters and D u/v buffers."""
+    from helpers import assert_close, load_golden
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    rec = fx["iters"][0]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(4, _free_port(), fname, d, True), nprocs=4, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(4)]
+    lr = fx["opt"]["lr_g"]
+    for r in range(4):
+        assert got[r]["amps"] == pytest.approx(rec["noise_amps"], rel=1e-4)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "rec_loss"):
+            assert_close(got[r]["out"][k], rec[k], 1e-3, "%s.rank%d.%s" % (fname, r, k))
+        assert_close(got[r]["out"]["errG"], rec["errG"], 3e-3, "%s.rank%d.errG" % (fname, r))
+        for k, v in rec["G_after"].items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-3, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        for k, v in rec["D_after"].items():
+            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                assert_close(got[r]["D"][k], v, 1e-3, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    for r in range(1, 4):
+        for k, v in got[0]["G"].items():
+            if O.is_param(k):
+                assert torch.equal(v, got[r]["G"][k]), "replicas diverged: " + k

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) gloo test of the multi-GPU step logic (hp_vae_gan_amd.multigpu.DistStageTrainer) on CPU.
+"""world_size-2/3 (pair mode) and 4/5 (quad mode) gloo tests of the multi-GPU step logic (hp_vae_gan_amd.multigpu.DistStageTrainer) on CPU.
 
 The distributed logic is backend-agnostic; here it is driven with a torch-CPU backend built on the oracle (tests may
 use the oracle) and compared with the single-process oracle train step on the same golden fixture: same losses, and
@@ -81,6 +81,53 @@ class TorchBackend:
     def noise(self, ref):
         return torch.randn(ref.shape)
 
+    def advance_sn(self, net, n):
+        P = net.P()
+        with torch.no_grad():
+            for _ in range(n):
+                for k in P:
+                    if k.endswith("weight_orig"):
+                        self.O.spectral_norm_weight(P[k], P[k[:-4] + "u"], P[k[:-4] + "v"], training=True)
+
+    def set_sync_bn(self, netG, sync):
+        """Batch-split BatchNorm for the oracle-backed stand-in: the oracle's batch_norm_train with the per-channel sums
+        exchanged through a differentiable all-reduce (test infrastructure; the product path is ops.BNActSync)."""
+        O = self.O
+        if not hasattr(O, "_bn_whole_batch"):
+            O._bn_whole_batch = O.batch_norm_train
+        if sync is None:
+            O.batch_norm_train = O._bn_whole_batch
+            return
+        allreduce, nranks = sync
+
+        class Sum(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                y = x.detach().clone()
+                allreduce(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                g = g.detach().clone()
+                allreduce(g)
+                return g
+
+        def bn(x, gamma, beta, running_mean=None, running_var=None):
+            dimsr = [0] + list(range(2, x.dim()))
+            shape = (1, -1) + (1,) * (x.dim() - 2)
+            n = (x.numel() // x.shape[1]) * nranks
+            xd = x.double()
+            mean = Sum.apply(xd.sum(dim=dimsr)) / n
+            var = Sum.apply(((xd - mean.view(shape)) ** 2).sum(dim=dimsr)) / n
+            y = ((xd - mean.view(shape)) / torch.sqrt(var.view(shape) + O.BN_EPS)).float() * gamma.view(shape) + beta.view(shape)
+            if running_mean is not None:
+                with torch.no_grad():
+                    running_mean.mul_(1 - O.BN_MOMENTUM).add_(O.BN_MOMENTUM * mean.detach().float())
+                    running_var.mul_(1 - O.BN_MOMENTUM).add_(O.BN_MOMENTUM * var.detach().float() * (n / max(n - 1, 1)))
+            return y
+        O.batch_norm_train = bn
+
     def optimizers(self, netG, netD, g_groups, lr_d, beta1):
         class _O:
             pass
@@ -119,7 +166,7 @@ def _groups(opt, netG):
     return out
 
 
-def _worker(rank, world, port, fname, outdir):
+def _worker(rank, world, port, fname, outdir, quad=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -135,11 +182,14 @@ def _worker(rank, world, port, fname, outdir):
     netG = OracleNet(fx["G_init"], opt, dims, "G")
     netD = OracleNet(fx["D_init"], opt, dims, "D") if fx["D_init"] is not None else None
     opt.Z_init_size = list(fx["iters"][0]["noise_init"].shape)
-    tr = multigpu.DistStageTrainer(opt, netG, netD, TorchBackend(opt), _groups(opt, netG))
+    tr = multigpu.DistStageTrainer(opt, netG, netD, TorchBackend(opt), _groups(opt, netG), quad=quad)
     rec = fx["iters"][0]
     gan = netD is not None
     noises = rec["noises"]
-    if gan:
+    if gan and quad:
+        # rank 0 also runs the calibration pass (first eps); rec ranks {0, 1} draw the rec eps, rand ranks the level noises
+        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else (noises[1:2] if rank == 1 else noises[2:]), "cpu")
+    elif gan:
         # reference draw order: [calibration eps], rec eps, then the level noises of the rand pass
         netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], "cpu")
     else:
@@ -148,7 +198,7 @@ def _worker(rank, world, port, fname, outdir):
     alpha = rec["alpha"] if rec["alpha"] is not None else None
     out = tr.step(fx["real"], fx["real_zero"], noise_init=rec["noise_init"], alpha=alpha)
     tr.sync_buffers()
-    if rank < 2:
+    if rank < (4 if quad else 2):
         torch.save({"out": {k: v for k, v in out.items()}, "amps": opt.Noise_Amps,
                     "G": {k: v.detach().clone() for k, v in netG.P().items()},
                     "D": {k: v.detach().clone() for k, v in netD.P().items()} if gan else None},
@@ -204,3 +254,33 @@ def test_distributed_step_matches_single_process(fname, world):
         for k in got[0]["D"]:
             if O.is_param(k):
                 assert torch.equal(got[0]["D"][k], got[1]["D"][k]), k
+
+
+@pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 4), ("step2d_gan_s2.pt", 5)])
+def test_quad_step_matches_single_process(fname, world):
+    """Four working ranks: generator passes split by sample with batch-split BatchNorm, discriminator work by sample and
+    task, spectral-norm power iterations replayed - same losses, parameters and D u/v buffers as the single process."""
+    from helpers import assert_close
+    from oracle import hpvg_oracle as O
+    fx, want, PG, PD, amps = _single_process(fname)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), fname, d, True), nprocs=world, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(4)]
+    lr = fx["opt"]["lr_g"]
+    for r in range(4):
+        assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
+            assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
+        for k, v in PG.items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        for k, v in PD.items():
+            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    for r in range(1, 4):
+        for k in got[0]["G"]:
+            if O.is_param(k):
+                assert torch.equal(got[0]["G"][k], got[r]["G"][k]), k
+        for k in got[0]["D"]:
+            if O.is_param(k):
+                assert torch.equal(got[0]["D"][k], got[r]["D"][k]), k
