@@ -19,13 +19,15 @@
 
 namespace {
 
+// source of zero padding for the LDS-DMA staging (out-of-image lanes read this word with stride 0)
+__device__ const float g_wzero[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 struct WgradArgs {
   const float* dy;
   const float* x;
   const float* in_scale;
   const float* in_shift;
   float* part;
-  const float* zeros;  // >= 4 bytes of zeros in global memory (source of padding for the LDS-DMA staging)
   int B, Cin, Cout, T, H, W;
   int Th, Tw, RS, DS, XS, QK, nth, ntw, S, ncb, nob;
   int in_lrelu;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh, gw = w0 + ww;
       const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
-      dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)a.zeros;
+      dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
       dstr[j] = ok ? cbytes : 0u;
     }
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
       const bool ok = hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)a.zeros;
+      xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
       xstr[j] = ok ? cbytes : 0u;
     }
   };
@@ -231,7 +233,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
 struct NarrowArgs {
   const float* wide;
   const float* narrow;
-  const float* zeros;
   float* part;
   int B, CW, CN, T, H, W;
   int Th, Tw, RS, DS, XPL, QK, nth, ntw, S, ntiles;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_narrow_kernel(const NarrowA
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh, gw = w0 + ww;
       const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
-      wptr[j] = ok ? (const char*)(wbp + gh * a.W + gw) : (const char*)a.zeros;
+      wptr[j] = ok ? (const char*)(wbp + gh * a.W + gw) : (const char*)g_wzero;
       wstr[j] = ok ? cbytes : 0u;
       const int gh2 = h0 + hh - 1, gw2 = w0 + ww - 1;
       nok[j] = hh < a.Th + 2 && gh2 >= 0 && gh2 < a.H && gw2 >= 0 && gw2 < a.W;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_narrow_kernel(const NarrowA
     float* dst = buf + 64 * DS + row * XPL + wave * 64;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      if (nln[j]) __builtin_amdgcn_global_load_lds((gptr_t)((valid && nok[j]) ? src + noff[j] : a.zeros), (lptr_t)(dst + j * 256), 4, 0, 0);
+      if (nln[j]) __builtin_amdgcn_global_load_lds((gptr_t)((valid && nok[j]) ? src + noff[j] : g_wzero), (lptr_t)(dst + j * 256), 4, 0, 0);
   };
 
   int tile = blockIdx.x;
@@ -588,9 +589,8 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
     if (S < 1) S = 1;
     if (ntiles < S) S = ntiles;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) return HPVG_ERR_LAUNCH;
     NarrowArgs na;
-    na.wide = nm == 0 ? dy : x; na.narrow = nm == 0 ? x : dy; na.zeros = (const float*)ws; na.part = (float*)((char*)ws + 256);
+    na.wide = nm == 0 ? dy : x; na.narrow = nm == 0 ? x : dy; na.part = (float*)((char*)ws + 256);
     na.B = B; na.CW = CW; na.CN = CN; na.T = T; na.H = H; na.W = W;
     na.Th = p.Th; na.Tw = p.Tw; na.RS = p.RS; na.DS = p.DS; na.XPL = p.XS; na.QK = p.QK; na.nth = p.nth; na.ntw = p.ntw;
     na.S = (int)S; na.ntiles = (int)ntiles;
@@ -625,9 +625,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   WgradArgs a;
   if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
   a.dy = dy; a.x = x; a.in_scale = in_scale; a.in_shift = in_shift;
-  a.zeros = (const float*)ws;                    // first 256 bytes of the workspace: zeros for padded positions
   a.part = (float*)((char*)ws + 256);
-  if (hipMemsetAsync(ws, 0, 256, (hipStream_t)stream) != hipSuccess) return HPVG_ERR_LAUNCH;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
   a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
