@@ -456,20 +456,25 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* 
 
 // per-channel sum over (b, spatial): out[c] = sum_b sum_s x[b][c][s]   (bias gradient)
 // two stages (grid (nsplit, C) partials in fp64, then one finishing thread per channel): reproducible, chip-filling
+template <int V>
 __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, int B, int C, long S, int nsplit,
                                                                    double* __restrict__ part) {
+  typedef typename HpvgVec<V>::type Vec;
   __shared__ double sh[4];
   const int c = blockIdx.y, k = blockIdx.x;
-  const long chunk = (S + nsplit - 1) / nsplit;
-  const long lo = (long)k * chunk, hi = (lo + chunk < S) ? lo + chunk : S;
+  const long SV = S / V;
+  const long chunk = (SV + nsplit - 1) / nsplit;
+  const long lo = (long)k * chunk, hi = (lo + chunk < SV) ? lo + chunk : SV;
   double acc = 0.0;
   for (int b = 0; b < B; ++b) {
-    const float* p = x + ((long)b * C + c) * S;
+    const Vec* p = reinterpret_cast<const Vec*>(x + ((long)b * C + c) * S);
     float loc = 0.f;
     int cnt = 0;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
-      loc += p[i];
-      if (++cnt == 32) { acc += loc; loc = 0.f; cnt = 0; }
+      const Vec v = p[i];
+#pragma unroll
+      for (int e = 0; e < V; ++e) loc += hpvg_vget<V>(v, e);
+      if (++cnt == 32 / V) { acc += loc; loc = 0.f; cnt = 0; }
     }
     acc += loc;
   }
@@ -673,7 +678,11 @@ int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, 
   if (want > 64) want = 64;
   const int ns = (int)want;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  switch (hpvg_vec_width(x, S)) {
+    case 4: hipLaunchKernelGGL(channel_sum_partial_kernel<4>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
+    case 2: hipLaunchKernelGGL(channel_sum_partial_kernel<2>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
+    default: hipLaunchKernelGGL(channel_sum_partial_kernel<1>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  }
   hipLaunchKernelGGL(channel_sum_finish_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, out);
   return hpvg_launch_status();
 }

@@ -30,7 +30,22 @@ static inline int hpvg_launch_status() {
 
 static inline int hpvg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// widest per-lane load (floats) the per-channel reduction kernels may use on rows of S floats starting at p: every row
+// start ((b*C + c)*S) and every chunk start must stay aligned to it
+static inline int hpvg_vec_width(const void* p, long S) {
+  const uintptr_t a = (uintptr_t)p;
+  if ((a & 15) == 0 && (S & 3) == 0) return 4;
+  if ((a & 7) == 0 && (S & 1) == 0) return 2;
+  return 1;
+}
+
 #ifdef __HIPCC__
+template <int V> struct HpvgVec;
+template <> struct HpvgVec<4> { typedef f32x4 type; };
+template <> struct HpvgVec<2> { typedef f32x2 type; };
+template <> struct HpvgVec<1> { typedef float type; };
+template <int V> __device__ __forceinline__ float hpvg_vget(const typename HpvgVec<V>::type& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float hpvg_vget<1>(const float& v, int) { return v; }
 __device__ __forceinline__ float hpvg_lrelu(float v) { return v > 0.f ? v : HPVG_LRELU_SLOPE * v; }
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Map the
