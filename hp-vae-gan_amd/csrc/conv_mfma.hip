@@ -92,12 +92,15 @@ constexpr int NJMAX = 4;  // (Th+2)*RS <= 1024
 struct SkTile { int b, t, h0, w0, mb0; };
 __device__ __forceinline__ SkTile sk_decode_tile(const ConvFwdArgs& a, int tile, int MB) {
   SkTile c;
+  // tile order: output-channel group fastest, then TIME, then the spatial tile.  Consecutive ids (= one XCD, thanks to
+  // hpvg_xcd_remap) are then the same spatial tile at neighbouring t: the input planes t-1, t, t+1 they share are fetched
+  // from HBM once and hit in that XCD's L2 for the other two (spatial-major order re-read every plane 3x: PMC)
   const int yb = tile % a.gridy;
   int r = tile / a.gridy;
+  c.t = r % a.T; r /= a.T;
   const int tw_i = r % a.ntw; r /= a.ntw;
-  const int th_i = r % a.nth; r /= a.nth;
-  c.t = r % a.T;
-  c.b = r / a.T;
+  const int th_i = r % a.nth;
+  c.b = r / a.nth;
   c.h0 = th_i * a.Th;
   c.w0 = tw_i * a.Tw;
   c.mb0 = yb * MB;
