@@ -193,3 +193,49 @@ def test_graph_replay_equals_eager(fname):
         # VAE stage: identical draws -> equal up to the float-atomic order of upsample_bwd and Adam's amplification of it
         assert_close(vb.float(), va.float(), 2e-2 if fx["D_init"] is not None else 1e-3, "graph.G." + k, atol=2 * lr if fx["D_init"] is not None else lr)  # conv biases feeding BN drift by +-lr per step
     assert b_tr.iteration == a_tr.iteration == 4
+
+
+@pytest.mark.parametrize("fname,iters", [("step3d_gan_s3.pt", 6), ("step3d_vae_s1.pt", 6)])
+def test_several_iterations_track_the_oracle(fname, iters):
+    """Longer horizon than the reference fixtures hold: N consecutive iterations of the same stage (optimizer moments and
+    step counts, BatchNorm running statistics, spectral-norm u/v and the calibrated amplitude all carried over) on the HIP
+    path and on the oracle, fed with the same fresh noise.  Adam's sign-flip chaos lets parameters
+    drift apart by O(lr) per step, so the losses are compared with a tolerance that grows with the iteration."""
+    from helpers import NoiseFeed, oracle_state, opt_from
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    rec0 = fx["iters"][0]
+    gan = fx["D_init"] is not None
+    g = torch.Generator().manual_seed(4242)
+    draws = []          # per iteration: (noise_init, [noises...], alpha)
+    for it in range(iters):
+        shapes = [t.shape for t in (rec0["noises"] if it == 0 else rec0["noises"][1:])]   # [1:]: no calibration pass
+        draws.append((torch.randn(rec0["noise_init"].shape, generator=g), [torch.randn(s, generator=g) for s in shapes],
+                      torch.rand(1, 1, generator=g) if gan else None))
+    # oracle
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    PG = oracle_state(fx["G_init"])
+    PD = oracle_state(fx["D_init"]) if gan else None
+    amps = list(fx["noise_amps_init"])
+    adam_g, adam_d, want = {}, {}, []
+    for it, (z, noises, alpha) in enumerate(draws):
+        feed = iter(noises)
+        if it == 0:
+            O.noise_amp_for_stage(PG, opt, fx["dims"], fx["scale_idx"], fx["real"], fx["real_zero"], amps, feed)
+        want.append(O.train_step(PG, PD, opt, fx["dims"], fx["scale_idx"], fx["real"], fx["real_zero"], z, feed,
+                                 alpha.reshape(()) if gan else None, amps, adam_g, adam_d))
+    # HIP: run_hip_stage drives fx["iters"]; give it our draws
+    fx2 = dict(fx)
+    fx2["iters"] = [dict(noise_init=z, noises=noises, alpha=alpha) for z, noises, alpha in draws]
+    keys = ("errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG") if gan else ("rec_vae_loss", "kl_loss", "total_loss")
+    for it, (rec, out, netG, netD, trainer) in enumerate(run_hip_stage(fx2)):
+        tol = 2e-3 * (1 + 2 * it)
+        for k in keys:
+            assert_close(out[k], want[it][k], tol, "%s[%d].%s" % (fname, it, k), atol=1e-5)
+    sd = netG.state_dict()
+    lr = fx["opt"]["lr_g"] * iters
+    worst = max(float((sd[k].float().cpu() - v.detach().float()).abs().max()) for k, v in PG.items() if O.is_param(k))
+    assert worst <= 3 * lr, "post-training G parameters drifted by %.3e (> 3 lr*N = %.3e)" % (worst, 3 * lr)
+    assert trainer.opt.Noise_Amps == pytest.approx(amps, rel=1e-4)
