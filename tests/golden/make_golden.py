@@ -157,7 +157,13 @@ def g_param_list(netG, opt, scale_idx):
             blocks = netG.body[-opt.train_depth:]
             plist += [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))} for i, b in enumerate(blocks)]
     else:
-        raise NotImplementedError
+        if len(netG.body) < opt.train_depth:
+            plist += [{"params": netG.encode.parameters(), "lr": opt.lr_g * (opt.lr_scale ** scale_idx)},
+                      {"params": netG.decoder.parameters(), "lr": opt.lr_g * (opt.lr_scale ** scale_idx)}]
+            plist += [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(netG.body) - 1 - i))} for i, b in enumerate(netG.body)]
+        else:
+            blocks = netG.body[-opt.train_depth:]
+            plist += [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))} for i, b in enumerate(blocks)]
     return plist
 
 
@@ -472,6 +478,10 @@ def main():
         'step2d_vae_s1.pt': lambda: with_kink_margin(lambda sd: run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=sd), 104, 2e-5),
         'baseline3d_s2.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=2, Gsteps=1, alpha=10.0, train_depth=1), 2, 1, seed=105),
         'sample3d_s3.pt': lambda: run_sampling(images, n3, make_opt(vae_levels=2), 3, 3, seed=106),
+        # non-default training depth: the last two blocks train (no detach between them, scaled learning rates), and
+        # --train-all with every level open (train_video.py:74-86, networks_3d.py:391-392)
+        'step3d_gan_s3_td2.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2, train_depth=2), 3, 3, 1, seed=107),
+        'step3d_gan_s2_all.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=1, train_all=True, train_depth=8), 3, 2, 1, seed=108),
     }
     want = sys.argv[1:] or ['tables.json'] + list(jobs)
     if 'tables.json' in want:

@@ -9,7 +9,8 @@ from helpers import RTOL, assert_close, bn_bias_atol, flat_to_named, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt"])
+@pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt",
+                                   "step3d_gan_s3_td2.pt", "step3d_gan_s2_all.pt"])
 def test_train_step_matches_reference(fname):
     fx = load_golden(fname)
     gan = fx["D_init"] is not None

@@ -143,7 +143,8 @@ def _run_stage(fname):
         yield fx, rec, out, PG, PD
 
 
-@pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt"])
+@pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt",
+                                   "step3d_gan_s3_td2.pt", "step3d_gan_s2_all.pt"])
 def test_train_step(fname):
     for it, (fx, rec, out, PG, PD) in enumerate(_run_stage(fname)):
         for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG"):
