@@ -10,7 +10,6 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import lib
 from .lib import call, ptr, stream
 
 _ws_cache = {}

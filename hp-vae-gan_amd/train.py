@@ -5,11 +5,9 @@ clip over ALL generator gradients, a fresh Adam per stage, D gradients of the G 
 
 Data loading, logging, tensorboard and checkpoint writing are out of scope: `data` is any iterable
 yielding `real` (stage 0) or `(real, real_zero)` device tensors."""
-import itertools
 
 import torch
 
-from . import ops
 from . import optim as hp_optim
 from . import utils
 from .modules import networks_2d, networks_3d

@@ -13,7 +13,6 @@ is driven by this script around the reference's own classes and functions.  Ever
 Only DATA is written (inputs + expected outputs, as torch tensors / python scalars); no reference source text."""
 import importlib.util
 import json
-import math
 import os
 import sys
 import types

@@ -135,7 +135,6 @@ def test_graph_replay_equals_eager(fname):
     """hipGraph capture of the iteration (StageTrainer.enable_graph): replays must produce what eager steps produce.
     Noise is pinned by a cycling noise_source so that both runs see identical draws; alpha is injected in the eager
     run and pinned in the graph run by seeding the device generator identically."""
-    import itertools
     from helpers import hip_opt
     from hp_vae_gan_amd import train as hp_train
     from hp_vae_gan_amd.modules import networks_3d

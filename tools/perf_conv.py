@@ -1,6 +1,6 @@
 """Micro-benchmark of the two MFMA conv kernels at a given pyramid-stage shape (development tool, not a test).
 usage: python tools/perf_conv.py [stage] [reps]"""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hp_vae_gan_amd
