@@ -45,8 +45,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int oblk = wave >> 1, cblk = wave & 1;
-  const int dt = blockIdx.y;
-  const int z = blockIdx.z;
+  // Workgroup ids: time tap fastest, then the persistent slot, inside the contiguous id range hpvg_xcd_remap gives each
+  // XCD.  The KT workgroups of a slot walk the SAME tile list (time-major, below), so at any moment they hold the same
+  // dY tile and the X planes t-1, t, t+1, which the neighbouring slots (tiles t-1, t+1 of the same spatial position)
+  // need as well: each plane is fetched from HBM once and hits in the XCD's L2 for its other readers.
+  const int nz = a.nob * a.ncb;
+  const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const int dt = L % KT;
+  const int slot = (L / KT) % a.S;
+  const int z = L / (KT * a.S);
   const int ob = z / a.ncb, cb = z % a.ncb;
   const int RS = a.RS, DS = a.DS, XS = a.XS;
   const int BUF = 64 * (DS + XS);
@@ -56,12 +63,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   int no = a.Cout - ob * 64; if (no > 64) no = 64;   // channels present in this 64-block
   int nc = a.Cin - cb * 64;  if (nc > 64) nc = 64;
 
-  // valid output time planes for this dt: the input plane t + dt - pt must exist
+  // every time tap walks all B*T*nth*ntw tiles; where the input plane t + dt - pt does not exist the X rows are read
+  // from the zero word (those products are zero; the taps 0 and KT-1 have that slack: their lists used to be shorter)
   const int pt = (KT == 3 ? 1 : 0);
-  const int t_lo = (dt < pt) ? (pt - dt) : 0;
-  const int t_hi = (a.T - 1 + pt - dt < a.T - 1) ? (a.T - 1 + pt - dt) : (a.T - 1);
-  const int tv = t_hi - t_lo + 1;
-  const int ntiles = tv > 0 ? a.B * tv * a.nth * a.ntw : 0;
+  const int ntiles = a.B * a.T * a.nth * a.ntw;
 
   f32x16 acc[9];
 #pragma unroll
@@ -90,16 +95,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   for (int j = 0; j < NJX; ++j) xln[j] = j * 256 + tid < XS;
   const unsigned cbytes = (unsigned)(cstride * 4);
   auto setup = [&](int tile) {
-    const int tw_i = tile % a.ntw;
-    int r = tile / a.ntw;
+    const int t = tile % a.T;  // time-major tile order
+    int r = tile / a.T;
+    const int tw_i = r % a.ntw;
+    r /= a.ntw;
     const int th_i = r % a.nth;
-    r /= a.nth;
-    const int t = t_lo + r % tv;
-    const int b = r / tv;
+    const int b = r / a.nth;
     const int tt = t + dt - pt;
+    const bool tok = tt >= 0 && tt < a.T;
     const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
     const float* dyb = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
-    const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + tt) * HW;
+    const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + (tok ? tt : 0)) * HW;
 #pragma unroll
     for (int j = 0; j < NJD; ++j) {
       const int p = j * 256 + tid;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
       const int p = j * 256 + tid;
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-      const bool ok = hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
       xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
       xstr[j] = ok ? cbytes : 0u;
     }
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     dma_x += XS;
   };
 
-  int tile = blockIdx.x;
+  int tile = slot;
   __syncthreads();  // zero fill done
   if (tile < ntiles) {
     setup(tile);
@@ -166,7 +172,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
       dma_begin(lds + (cur ^ 1) * BUF);
       cnext = 0;
     }
-    if (active) {
+    // a tile whose input plane t + dt - pt lies outside the clip contributes nothing: no MFMAs, only the staging of the
+    // next tile (uniform per workgroup)
+    const int tt_cur = tile % a.T + dt - pt;
+    if (active && tt_cur >= 0 && tt_cur < a.T) {
       const float* dl = bufc + (oblk * 32 + l31) * DS + half;
       const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + half;
       // two register sets: the LDS reads of step st+1 are issued before the MFMAs of step st (1 wave per SIMD:
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   }
 
   // ---- partial slab: part[s][dt][z][tap9][o64][c64]
-  float* pp = a.part + ((((long)blockIdx.x * KT + dt) * gridDim.z + z) * 9) * 4096;
+  float* pp = a.part + ((((long)slot * KT + dt) * nz + z) * 9) * 4096;
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -635,7 +644,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
   a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(p.S, KT, p.nob * p.ncb);
+  const dim3 grid(p.S * KT * p.nob * p.ncb);
   const int njd = p.DS > 256 ? 2 : 1, njx = p.XS > 256 ? 2 : 1;
 #define HPVG_WG_LAUNCH(K, D, X)                                                                                        \
   {                                                                                                                    \
