@@ -62,7 +62,9 @@ struct ConvFwdArgs {
   const float* in_shift;
   float* y;
   int B, Cin, Cout, T, H, W;
-  int Th, Tw, RS, PL, nth, ntw, nblocks, nchunk, mbtot, nj;
+  // tile = `L` consecutive positions of the row-flattened band (W split into ntw bands of Tw columns, LDS row stride
+  // RS = Tw + 2), nrange tiles per band and plane; Th only for the 2-D tiles of the narrow kernel (L = Th * RS)
+  int Th, Tw, RS, PL, L, qstride, nrange, ntw, nblocks, nchunk, mbtot, nj;  // tile r of a band starts at r * qstride
   int in_lrelu, out_lrelu;
   // schedule: tiles [0, ndp*S) are data-parallel rounds (round k: tile k*S + g), tiles [skbase, ntl) are cut into
   // (tile, channel-chunk) items dealt evenly over the S workgroups (stream-K)
@@ -89,7 +91,7 @@ constexpr int NJMAX = 4;  // (Th+2)*RS <= 1024
 // Measured on MI355X (tools/trace_conv.py, per-workgroup timeline): one workgroup per CU already saturates the matrix
 // pipe (2 per CU: +3 %); the sustained shader clock under this load is 2.03-2.07 GHz with real data (2.29 GHz when the
 // operands are zeros), i.e. the fp32 MFMA ceiling of the part is ~134 TFLOP/s, not the 157.3 of 2.4 GHz.
-struct SkTile { int b, t, h0, w0, mb0; };
+struct SkTile { int b, t, q0, w0, mb0; };
 __device__ __forceinline__ SkTile sk_decode_tile(const ConvFwdArgs& a, int tile, int MB) {
   SkTile c;
   // tile order: output-channel group fastest, then TIME, then the spatial tile.  Consecutive ids (= one XCD, thanks to
@@ -99,9 +101,9 @@ __device__ __forceinline__ SkTile sk_decode_tile(const ConvFwdArgs& a, int tile,
   int r = tile / a.gridy;
   c.t = r % a.T; r /= a.T;
   const int tw_i = r % a.ntw; r /= a.ntw;
-  const int th_i = r % a.nth;
-  c.b = r / a.nth;
-  c.h0 = th_i * a.Th;
+  const int r_i = r % a.nrange;
+  c.b = r / a.nrange;
+  c.q0 = r_i * a.qstride;
   c.w0 = tw_i * a.Tw;
   c.mb0 = yb * MB;
   return c;
@@ -113,19 +115,21 @@ struct StageSlots {
   unsigned bofs[NJMAX];   // the same in bytes (planes are < 4 GB)
   unsigned okmask, wmask; // bit j: slot j lies inside the image / inside the staged plane
 };
-__device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int h0, int w0, int tid) {
+__device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int q0, int w0, int tid) {
+  // slot p holds position P = q0 + p of the zero-padded, row-flattened band: row P / RS - 1, column w0 + P % RS - 1
   StageSlots sl;
   sl.okmask = 0;
   sl.wmask = 0;
-  const int RS = a.RS, plload = (a.Th + 2) * RS;
+  const int RS = a.RS, plload = a.L + 2 * RS + 2;
 #pragma unroll
   for (int j = 0; j < NJMAX; ++j) {
     const int p = j * 256 + tid;
     sl.gofs[j] = 0;
     sl.bofs[j] = 0;
     if (j < a.nj && p < plload) {
-      const int hh = p / RS, ww = p - hh * RS;
-      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      const int P = q0 + p;
+      const int hh = P / RS, ww = P - hh * RS;
+      const int gh = hh - 1, gw = w0 + ww - 1;
       sl.wmask |= 1u << j;
       if (gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
         sl.okmask |= 1u << j;
@@ -259,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       it += n;
     }
     const SkTile tc = sk_decode_tile(a, tile, MB);
-    const int b = tc.b, t = tc.t, h0 = tc.h0, w0 = tc.w0, mb0 = tc.mb0;
+    const int b = tc.b, t = tc.t, q0 = tc.q0, w0 = tc.w0, mb0 = tc.mb0;
 
-    const StageSlots sl = conv_stage_slots(a, h0, w0, tid);
+    const StageSlots sl = conv_stage_slots(a, q0, w0, tid);
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -353,9 +357,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
     for (int i = 0; i < NB; ++i) {
       const int blk = wave + 4 * i;
       const int q = blk * 32 + l31;
-      const int hh = q / RS, ww = q - hh * RS;
-      const int gh = h0 + hh, gw = w0 + ww;
-      const bool ok = blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W;
+      const int Q = q0 + q;
+      const int gh = Q / RS, ww = Q - gh * RS;
+      const int gw = w0 + ww;
+      const bool ok = q < a.L && ww < a.Tw && gh < a.H && gw < a.W;
       if (!ok) continue;
       const long sp = (long)t * HW + (long)gh * a.W + gw;
 #pragma unroll
@@ -394,9 +399,10 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
   const int RS = a.RS;
   const int blk = wave + 4 * i;
   const int q = blk * 32 + l31;
-  const int hh = q / RS, ww = q - hh * RS;
-  const int gh = tc.h0 + hh, gw = tc.w0 + ww;
-  if (!(blk < a.nblocks && ww < a.Tw && hh < a.Th && gh < a.H && gw < a.W)) return;
+  const int Q = tc.q0 + q;
+  const int gh = Q / RS, ww = Q - gh * RS;
+  const int gw = tc.w0 + ww;
+  if (!(q < a.L && ww < a.Tw && gh < a.H && gw < a.W)) return;
   const long slab = (long)MB * NB * 16 * 256;
   float v[16];
 #pragma unroll
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const ConvFwdArgs a
 
   const int tile = hpvg_xcd_remap(blockIdx.x, gridDim.x);
   const SkTile tc = sk_decode_tile(a, tile, 1);
-  const int b = tc.b, t = tc.t, h0 = tc.h0, w0 = tc.w0;
+  const int b = tc.b, t = tc.t, h0 = tc.q0 / RS, w0 = tc.w0;  // 2-D tiles here: L = Th * RS
   const int plload = (a.Th + 2) * RS;
   const int nblk = (plload + 31) / 32;
   const float* xb0 = a.x + (long)b * a.Cin * a.T * HW;
@@ -602,7 +608,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
 inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
 
 struct Plan {
-  int Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, nj;
+  int Th, Tw, RS, PL, L, qstride, nrange, ntw, nblocks, NB, MB, gridy, nj;  // Th != 0 only for the narrow kernel's 2-D tiles
   size_t lds;  // bytes of the LDS tile buffer
 };
 
@@ -625,9 +631,10 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
   // development knobs: restrict the search to one NB / MB
   static const int only_nb = [] { const char* e = getenv("HPVG_PLAN_NB"); return e ? atoi(e) : 0; }();
   static const int only_mb = [] { const char* e = getenv("HPVG_PLAN_MB"); return e ? atoi(e) : 0; }();
-  for (int MB = (mbtot >= 2 ? 2 : 1); MB >= 1; --MB) {
-    if (only_mb && MB != only_mb && mbtot >= 2 && !narrow) continue;
-    const int gridy = hpvg_cdiv(mbtot, MB);
+  if (narrow) {
+    // 2-D tiles (Th x Tw) for conv_narrow_kernel: a GEMM over the tile + halo positions, one workgroup per tile: blocks
+    // of 32 positions over 4 waves, K steps of 64 cycles each, ~3 us of epilogue; the P image (9*Cout rows) must leave
+    // room for >= 4 workgroups per CU (they hide the load latency)
     for (int Tw = 1; Tw <= W; ++Tw) {
       const int ntw = hpvg_cdiv(W, Tw);
       if (Tw != hpvg_cdiv(W, ntw)) continue;  // only balanced splits of W
@@ -635,30 +642,72 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
       for (int Th = 1; Th <= H; ++Th) {
         const int nth = hpvg_cdiv(H, Th);
         if (Th != hpvg_cdiv(H, nth)) continue;
-        const int qmax = (Th - 1) * RS + Tw - 1;
-        const int nblocks = qmax / 32 + 1;
-        if (nblocks > 16) break;
+        const int nblk_h = hpvg_cdiv((Th + 2) * RS, 32);
         if ((Th + 2) * RS > NJMAX * 256) break;
-        const int rounds = hpvg_cdiv(nblocks, 4);
-        const int NB = rounds <= 1 ? 1 : (rounds == 2 ? 2 : 4);
+        if ((size_t)(9 * Cout) * ((size_t)nblk_h * 32 + 1) * sizeof(float) > 38 * 1024) continue;
+        const long ntl = (long)B * T * nth * ntw;
+        const double per_tile = hpvg_cdiv(nblk_h, 4) * (double)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 0.033 + 3.0;
+        const double waves = ntl <= CONV_SLOTS ? 1.0 : (double)ntl / (double)CONV_SLOTS;
+        const double cost = waves * per_tile + 1e-3 * (double)ntl;
+        if (cost < best_cost - 1e-9) {
+          best_cost = cost;
+          best = Plan{Th, Tw, RS, (Th + 2) * RS, Th * RS, Th * RS, nth, ntw, hpvg_cdiv(Th * RS, 32), 4, 1, 1, hpvg_cdiv((Th + 2) * RS, 256), 0};
+        }
+      }
+    }
+    return best;
+  }
+  // MFMA kernel: W is cut into ntw balanced bands of Tw columns; a band plane, flattened row by row with stride RS = Tw+2
+  // (its two halo columns are the junk GEMM columns), is cut into nrange balanced ranges of L <= NB*128 positions.  Wide
+  // bands waste few junk columns, and a range - unlike a whole number of rows - fills its 32-position blocks.
+  for (int MB = (mbtot >= 2 ? 2 : 1); MB >= 1; --MB) {
+    if (only_mb && MB != only_mb && mbtot >= 2) continue;
+    const int gridy = hpvg_cdiv(mbtot, MB);
+    for (int ntw = 1; ntw <= W; ++ntw) {
+      const int Tw = hpvg_cdiv(W, ntw);
+      if (ntw > 1 && hpvg_cdiv(W, ntw - 1) == Tw) continue;  // same band width as the previous ntw: more bands, no gain
+      const int RS = Tw + 2;
+      const long flat = (long)(H - 1) * RS + Tw;  // flattened positions that hold outputs
+      // candidate tiles of this band.  3x3x3: balanced ranges of at most NB*128 positions.  3x3 (a third of the MFMA work
+      // per staged plane, so the cost constants fitted on 3x3x3 launches do not rank these well): whole rows only, the
+      // tile family the 2-D path was tuned and measured with.
+      const int ncand = KT == 3 ? 3 : H;
+      for (int cand = 0; cand < ncand; ++cand) {
+        int NB, L, nrange, qstride;
+        if (KT == 3) {
+          NB = 1 << cand;
+          nrange = hpvg_cdiv(flat, NB * 128);
+          L = hpvg_cdiv(flat, nrange);
+          qstride = L;
+        } else {
+          const int Th = cand + 1;
+          nrange = hpvg_cdiv(H, Th);
+          if (Th != hpvg_cdiv(H, nrange)) continue;  // only balanced splits of H
+          L = Th * RS;
+          const int nblk = (L - 3) / 32 + 1;          // last output position of the tile: (Th-1)*RS + Tw - 1
+          if (nblk > 16) break;
+          const int rounds = hpvg_cdiv(nblk, 4);
+          NB = rounds <= 1 ? 1 : (rounds == 2 ? 2 : 4);
+          qstride = L;
+          if (L > NB * 128) L = NB * 128;             // the (at most two) positions cut off are halo columns
+        }
         if (only_nb && NB != only_nb) continue;
-        int PL = (Th + 2) * RS;
-        const int need = 128 * NB + 2 * RS + 2;
-        if (PL < need) PL = need;
+        const int Lmax = NB * 128;
+        const int plload = L + 2 * RS + 2;
+        if (plload > NJMAX * 256) continue;
+        const int PL = Lmax + 2 * RS + 2;  // lanes past L still read (junk) operands inside the buffer
         const size_t lds = (size_t)CC * KT * PL * sizeof(float);
         if (lds > 80 * 1024) continue;
-        const long ntl = (long)B * T * nth * ntw * gridy;
-        const double stage_us = 0.0065 * (Th + 2) * RS;
+        const long ntl = (long)B * T * nrange * ntw * gridy;
+        const double stage_us = 0.0065 * plload;
         double cost;
-        if (narrow) {
-          // GEMM over the tile + halo positions, one workgroup per tile: blocks of 32 positions over 4 waves, K steps of
-          // 64 cycles each, ~3 us of epilogue; the P image (9*Cout rows) must leave room for two workgroups per CU
-          const int nblk_h = hpvg_cdiv((Th + 2) * RS, 32);
-          if ((size_t)(9 * Cout) * ((size_t)nblk_h * 32 + 1) * sizeof(float) > 38 * 1024) continue;  // >= 4 workgroups per CU hide the load latency
-          const double per_tile = hpvg_cdiv(nblk_h, 4) * (double)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 0.033 + 3.0;
-          const double waves = ntl <= CONV_SLOTS ? 1.0 : (double)ntl / (double)CONV_SLOTS;
-          cost = waves * per_tile + 1e-3 * (double)ntl;
-        } else if (streamk) {
+        if (streamk) {
+          // S co-resident workgroups share the (tile, chunk) items evenly.  Cost in us, constants fitted to measured
+          // launches (tools/perf_conv.py, stages 5-9, within 5 %): an item costs its MFMA rounds (6.5 us per 32-position
+          // x 32-channel x 8-channel-chunk round when two workgroups share the CU's matrix pipe, half that when alone)
+          // + ~8 us of staging / barrier work the co-resident workgroup does not hide + the input planes it stages;
+          // tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block, written by
+          // the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth)
           const long items_tot = ntl * nchunk;
           const long S = items_tot < CONV_SLOTS ? items_tot : CONV_SLOTS;
           const long ndp = ntl / S;
@@ -674,7 +723,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
           }
           cost = items * per_item + tiles * 0.8 * NB * MB + parts * 5.5 * NB * MB + 1e-4 * (double)ntl;
         } else {
-          // whole tiles per CU: pairs run together, an odd one runs alone at the end
+          // one workgroup per tile: whole tiles per CU, pairs run together, an odd one runs alone at the end
           const long per_cu = (ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
           const double tile_paired = nchunk * ((double)NB * MB * 6.5 + 8.5 + stage_us) + 0.8 * NB * MB;
           const double tile_alone = nchunk * ((double)NB * MB * 3.4 + 6.0 + stage_us) + 0.8 * NB * MB;
@@ -682,7 +731,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
         }
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
-          best = Plan{Th, Tw, RS, PL, nth, ntw, nblocks, NB, MB, gridy, hpvg_cdiv((Th + 2) * RS, 256), lds};
+          best = Plan{0, Tw, RS, PL, L, qstride, nrange, ntw, hpvg_cdiv(L, 32), NB, MB, gridy, hpvg_cdiv(plload, 256), lds};
         }
       }
     }
@@ -834,17 +883,17 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   const int nchunk = hpvg_cdiv(Cin, CC);
   bool streamk = !sk_off && ws != nullptr && !conv_is_narrow(Cin, Cout);
   Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk);
-  if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
-  int ntl = B * T * p.nth * p.ntw * p.gridy;
+  if (p.L == 0) return HPVG_ERR_UNSUPPORTED;
+  int ntl = B * T * p.nrange * p.ntw * p.gridy;
   if (streamk && ws_bytes < conv_sk_ws_bytes(p, conv_sk_grid(ntl, nchunk))) {
     streamk = false;
     p = plan_conv(B, Cin, Cout, T, H, W, KT, false);
-    ntl = B * T * p.nth * p.ntw * p.gridy;
+    ntl = B * T * p.nrange * p.ntw * p.gridy;
   }
   ConvFwdArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
-  a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.nth = p.nth; a.ntw = p.ntw; a.nblocks = p.nblocks;
+  a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.L = p.L; a.qstride = p.qstride; a.nrange = p.nrange; a.ntw = p.ntw; a.nblocks = p.nblocks;
   a.nchunk = nchunk;
   a.mbtot = hpvg_cdiv(Cout, 32);
   a.nj = p.nj;
@@ -869,17 +918,18 @@ size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
   if (conv_is_narrow(Cin, Cout)) return 0;
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
-  if (p.Th == 0) return 0;
-  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nth * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin))));
+  if (p.L == 0) return 0;
+  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nrange * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin))));
 }
 
 // Debug/introspection: the tile plan of the stream-K launch (for tests and DESIGN.md tables).
-// out[0..9] = Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds_bytes, ntiles
+// out[0..9] = L (positions per tile), Tw (band width), nrange (tiles per band plane), ntw (bands), nblocks, NB, MB, gridy,
+// lds_bytes, ntiles
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
   if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
-  out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
-  out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
+  out[0] = p.L; out[1] = p.Tw; out[2] = p.nrange; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
+  out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nrange * p.ntw;
   return HPVG_OK;
 }
 

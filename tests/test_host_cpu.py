@@ -31,9 +31,11 @@ def test_size_queries_and_plans_run_without_gpu():
     out = (ctypes.c_int * 10)()
     for (B, Ci, Co, T, H, W, KT) in [(2, 64, 64, 13, 144, 256, 3), (2, 64, 64, 4, 18, 33, 3), (2, 3, 64, 1, 192, 256, 1), (2, 64, 3, 7, 91, 162, 3)]:
         assert hplib.call("hpvg_conv_fwd_plan", B, Ci, Co, T, H, W, KT, out) == 0
-        Th, Tw, nth, ntw, nblocks, NB, MB, gridy, lds, ntiles = list(out)
-        assert Th >= 1 and Tw >= 1 and nth * Th >= H and ntw * Tw >= W and nblocks <= 4 * NB and lds <= 160 * 1024
-        assert ntiles == B * T * nth * ntw
+        L, Tw, nrange, ntw, nblocks, NB, MB, gridy, lds, ntiles = list(out)
+        # tiles = ranges of L flattened positions (row stride Tw + 2) of a band of Tw columns
+        assert L >= 1 and Tw >= 1 and ntw * Tw >= W and nrange * L >= (H - 1) * (Tw + 2) + Tw
+        assert nblocks <= 4 * NB and nblocks * 32 >= L and lds <= 160 * 1024
+        assert ntiles == B * T * nrange * ntw
         assert hplib.call("hpvg_conv_bwd_weight_plan", B, Ci, Co, T, H, W, KT, out) == 0
         assert out[0] >= 1 and out[8] <= 160 * 1024 and out[5] >= 1
         assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT) > 0
