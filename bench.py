@@ -27,7 +27,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
 # collected separately and committed as profiles/r01_pmc_traffic_stage9.csv; bench.py cannot run the profiler itself.
-MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 8.88e8}  # conv_mfma_kernel 8.505e8 + conv_fixup_kernel 3.8e7
+MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.150e9}  # conv_mfma_kernel 9.77e8 + conv_fixup_kernel 1.73e8 (440 of 1976 tiles cut)
 
 
 CONFIG = "video"  # set by --config: "video" = BASELINE configs[2] (metric config), "image" = configs[1] (2-D path)
