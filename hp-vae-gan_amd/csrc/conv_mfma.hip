@@ -745,19 +745,29 @@ inline bool conv_is_narrow(int Cin, int Cout) { return Cout <= 4 && Cin > 4; }
 Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
   const bool narrow = conv_is_narrow(Cin, Cout);
   if (narrow) streamk = false;
+  // open-addressing table (a ten-stage run touches ~150 distinct shapes; the search is up to ~100 us for wide 2-D images)
   struct Key { int B, Cin, Cout, T, H, W, KT, sk; };
-  struct Entry { Key k; Plan p; };
-  static thread_local Entry cache[128];
-  static thread_local int used = 0;
+  struct Entry { Key k; Plan p; bool used; };
+  constexpr int NSLOT = 2048;
+  static thread_local Entry cache[NSLOT];
+  static thread_local int filled = 0;
   const Key k{B, Cin, Cout, T, H, W, KT, streamk ? 1 : 0};
-  for (int i = 0; i < used; ++i) {
-    const Key& c = cache[i].k;
-    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.sk == k.sk)
-      return cache[i].p;
+  unsigned h = 2166136261u;
+  for (int v : {B, Cin, Cout, T, H, W, KT, k.sk}) h = (h ^ (unsigned)v) * 16777619u;
+  for (int probe = 0; probe < NSLOT; ++probe) {
+    Entry& e = cache[(h + probe) & (NSLOT - 1)];
+    if (!e.used) {
+      const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
+      if (filled < NSLOT / 2) {  // keep the table sparse; past that, shapes are simply planned again
+        e.k = k; e.p = p; e.used = true;
+        ++filled;
+      }
+      return p;
+    }
+    const Key& c = e.k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.sk == k.sk) return e.p;
   }
-  const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
-  if (used < 128) cache[used++] = Entry{k, p};
-  return p;
+  return plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
 }
 
 // Launch of S workgroups.  The dynamic LDS request is padded to 56 KB so that a third workgroup never fits on a CU:

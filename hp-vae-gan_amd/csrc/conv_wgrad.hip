@@ -542,16 +542,26 @@ WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
 
 WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   struct Key { int B, Cin, Cout, T, H, W, KT; };
-  struct Entry { Key k; WPlan p; };
-  static thread_local Entry cache[128];
-  static thread_local int used = 0;
-  for (int i = 0; i < used; ++i) {
-    const Key& c = cache[i].k;
-    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return cache[i].p;
+  struct Entry { Key k; WPlan p; bool used; };
+  constexpr int NSLOT = 2048;
+  static thread_local Entry cache[NSLOT];
+  static thread_local int filled = 0;
+  unsigned h = 2166136261u;
+  for (int v : {B, Cin, Cout, T, H, W, KT}) h = (h ^ (unsigned)v) * 16777619u;
+  for (int probe = 0; probe < NSLOT; ++probe) {
+    Entry& e = cache[(h + probe) & (NSLOT - 1)];
+    if (!e.used) {
+      const WPlan p = plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
+      if (filled < NSLOT / 2) {
+        e.k = Key{B, Cin, Cout, T, H, W, KT}; e.p = p; e.used = true;
+        ++filled;
+      }
+      return p;
+    }
+    const Key& c = e.k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return e.p;
   }
-  const WPlan p = plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
-  if (used < 128) cache[used++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
-  return p;
+  return plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
 }
 
 // narrow path selection: 0 = head (Cin <= 4), 1 = tail (Cout <= 4), -1 = full kernel
