@@ -14,6 +14,7 @@ from torch.nn import init
 
 from .. import ops
 from .. import utils as hp_utils
+from ..slab import conv_with_halo
 
 
 def _kernel_shape(dims):
@@ -36,7 +37,13 @@ class Conv(nn.Module):
         bound = 1 / math.sqrt(fan_in)
         init.uniform_(self.bias, -bound, bound)
 
+    # multi-GPU: slab.Halo when this layer's level is cut into row slabs over neighbouring ranks (multigpu.py sets it)
+    halo = None
+
     def forward(self, x, act=False):
+        if self.halo is not None:
+            assert self.padding == 1, "row slabs are implemented for the 'same' convolutions of the HP-VAE-GAN path"
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, self.weight, self.bias, act))
         y = ops.Conv.apply(x, self.weight, self.bias, act)
         return y if self.padding == 1 else crop_border(y)
 
@@ -75,8 +82,13 @@ class SNConv(nn.Module):
     def effective_weight(self):
         return ops.SpectralNormWeight.apply(self.weight_orig, self.weight_u, self.weight_v, self.training, 1e-12)
 
+    halo = None  # as Conv.halo
+
     def forward(self, x, act=False):
-        return ops.Conv.apply(x, self.effective_weight(), self.bias, act)
+        w = self.effective_weight()
+        if self.halo is not None:
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act))
+        return ops.Conv.apply(x, w, self.bias, act)
 
 
 class BatchNorm(nn.Module):
@@ -92,8 +104,9 @@ class BatchNorm(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    # multi-GPU: (allreduce callable, number of ranks) when the batch is split over a process group (multigpu.py sets
-    # it on every BatchNorm of a generator whose passes are sharded by sample); None = the whole batch is local
+    # multi-GPU: (allreduce callable, number of ranks, total count or None) when the batch - and, on row slabs, the
+    # image - is split over a process group (multigpu.py sets it on the BatchNorms of a sharded generator pass): the
+    # statistics are over `total count` elements per channel (None: ranks x the local count); None = everything is local
     sync = None
 
     def forward(self, r, lrelu=True):
@@ -101,7 +114,8 @@ class BatchNorm(nn.Module):
             self.num_batches_tracked.add_(1)
             if self.sync is not None:
                 return ops.BNActSync.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
-                                           self.eps, lrelu, self.sync[0], self.sync[1])
+                                           self.eps, lrelu, self.sync[0], self.sync[1],
+                                           self.sync[2] if len(self.sync) > 2 else None)
             return ops.BNAct.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
                                    lrelu)
         with torch.no_grad():
@@ -225,6 +239,7 @@ class GeneratorHPVAEGAN(nn.Module):
         self.decoder = _seven_conv_stack(dims, opt.latent_dim, N, opt, opt.padd_size)
         self.body = nn.ModuleList([])
         self.noise_source = None
+        self.slab = None  # multi-GPU: slab.SlabPlan when the upper levels of this pass are cut into row slabs
 
     def init_next_stage(self):
         if len(self.body) == 0:
@@ -278,11 +293,18 @@ class GeneratorHPVAEGAN(nn.Module):
                 ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *size))
                 noise = self._noise_like(ref)
                 up, up_noisy = ops.UpsampleAC.apply(x_prev_out, tuple(size), noise, float(noise_amp[idx + 1]))
-                x_prev = block(up_noisy)
             else:
-                up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
-                x_prev = block(up)
-            x_prev_out = ops.TanhRes.apply(x_prev, up)
+                up = up_noisy = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
+            slab = self.slab if (self.slab is not None and self.slab.covers(idx + 1)) else None
+            if slab is not None:
+                # this level runs on this rank's row slab (its convs carry the halo swaps, its BatchNorms sum over the
+                # slab ranks); the 3-channel upsampled input was cheap to make whole, and the whole output is put back
+                # together for the next level's upsample.  The last level stays a slab: the losses are separable.
+                up = slab.cut(up)
+                up_noisy = slab.cut(up_noisy) if inject else up
+            x_prev_out = ops.TanhRes.apply(block(up_noisy), up)
+            if slab is not None and idx + 1 < len(self.body):
+                x_prev_out = slab.gather(x_prev_out, size[-2])
         return x_prev_out
 
 

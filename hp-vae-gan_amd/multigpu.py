@@ -31,7 +31,15 @@ each pass pair (ops.BNActSync: a 2 x C double all-reduce per BatchNorm forward a
 Rank (1, b) makes fake[b], keeps the gradient-penalty and the G-step critic work of sample b, and ships fake[b] once to
 rank (0, b), which evaluates D(real[b]) and D(fake[b]).  No gradient crosses ranks except inside the all-reduces.
 Per-rank work at the finest stage drops from ~36 to ~19.5 conv-units of 72 (SURVEY 8e numbers), i.e. <= 3.7x over one
-GPU; early stages (launch / latency bound) stay on two ranks.  Ranks >= 4 idle (spatial decomposition is the next step).
+GPU; early stages (launch / latency bound) stay on two ranks.
+
+Eight ranks ("oct" mode, the finest stages): each of the four (pass, sample) jobs is additionally cut into two ROW SLABS
+of the image (slab.py) - rank = 2*(2*pass + sample) + slab.  The slabbed part is where the work is: the discriminator
+(all of its evaluations) and the upper `slab_levels` generator levels; the lower generator levels are small and are
+replicated on the two slab ranks (their backward splits by linearity, so the weight-gradient all-reduce still adds up to
+the whole gradient).  New traffic: one boundary row per conv layer and direction to the slab neighbour (point to point,
+<= 0.85 MB), BatchNorm sums over the four ranks of a pass on slabbed levels, and a 3-channel all-reduce per slabbed
+level boundary.  Losses are means over (batch, voxels): every rank contributes mean(own slab) * (own rows / rows).
 
 The arithmetic is delegated to a `backend` (HipBackend below: the gfx950 kernels; the gloo tests plug in a torch-CPU
 backend built on the oracle) so that the distributed logic is testable without a GPU."""
@@ -79,6 +87,20 @@ def broadcast(t, src, group=None):
         t.copy_(h)
     else:
         dist.broadcast(t, src=src, group=group)
+
+
+def pair_swap(peer, group=None):
+    """swap(t) -> the tensor `peer` (global rank) passed to its matching swap (same shape): one send + one receive, point
+    to point, issued together (no ordering deadlock).  `group`: the two-rank process group of the pair, so that on RCCL
+    the communicator behind the swap is set up by these two ranks alone."""
+    def swap(t):
+        staged = _host_staged() and t.is_cuda
+        src = t.cpu() if staged else t
+        got = torch.empty_like(src)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, peer, group), dist.P2POp(dist.irecv, got, peer, group)]):
+            w.wait()
+        return got.to(t.device) if staged else got
+    return swap
 
 
 class HipBackend:
@@ -145,6 +167,24 @@ class HipBackend:
                 m.sync = sync
 
 
+    def set_slab(self, netG, netD, plan, level_sync=None):
+        """plan = slab.SlabPlan or None: row slabs on the generator levels the plan covers (halo swaps on their convs,
+        BatchNorm sums per `level_sync(level)`) and on every conv of the discriminator."""
+        from .modules._nets import BatchNorm, Conv, SNConv
+        netG.slab = plan
+        for k, block in enumerate(netG.body):
+            on = plan is not None and plan.covers(k + 1)
+            for m in block.modules():
+                if isinstance(m, (Conv, SNConv)):
+                    m.halo = plan.halo if on else None
+                elif isinstance(m, BatchNorm) and on:
+                    m.sync = level_sync(k + 1)
+        if netD is not None:
+            for m in netD.modules():
+                if isinstance(m, (Conv, SNConv)):
+                    m.halo = plan.halo if plan is not None else None
+
+
 _GROUPS = {}
 
 
@@ -163,7 +203,7 @@ class DistStageTrainer:
     """One pyramid stage on `world` ranks (see module docstring).  Mirrors train.StageTrainer.step().
     quad=True (needs world >= 4): generator passes and discriminator work over four ranks."""
 
-    def __init__(self, opt, netG, netD, backend, g_groups, group=None, quad=False):
+    def __init__(self, opt, netG, netD, backend, g_groups, group=None, quad=False, slabs=1, slab_levels=2):
         self.opt, self.netG, self.netD, self.be = opt, netG, netD, backend
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
@@ -171,14 +211,27 @@ class DistStageTrainer:
         if self.is_gan and opt.batch_size != 2:
             raise NotImplementedError("the batch split of the discriminator work assumes batch_size == 2 (reference default)")
         self.quad = bool(quad) and self.is_gan and self.world >= 4
-        nwork = 4 if self.quad else 2
+        # oct mode: the four (pass, sample) jobs of quad mode, each on `slabs` row slabs (rank = slabs*job + slab)
+        self.nh = int(slabs) if (self.quad and int(slabs) > 1 and self.world >= 4 * int(slabs)) else 1
+        if self.nh not in (1, 2):
+            raise NotImplementedError("row slabs are wired for two slabs per (pass, sample) job (8 ranks)")
+        self.slab_levels = int(slab_levels)
+        nwork = (4 * self.nh) if self.quad else 2
+        self.nwork = nwork
         self.active = self.rank < nwork or not self.is_gan     # GAN stages: two (four) working ranks
         # collectives of a GAN stage run over the working ranks only (every rank creates every group, in this order)
         self.pair = subgroup([0, 1]) if self.world > 2 else None
         if self.world >= 4:
             self.g_rand = subgroup([2, 3])
             self.g_quad = subgroup([0, 1, 2, 3])
+        if self.world >= 8:
+            self.g_oct = subgroup(range(8))
+            self.g_pass4 = [subgroup(range(4 * p, 4 * p + 4)) for p in range(2)]                     # one generator pass
+            self.g_samples = [[subgroup([4 * p + h, 4 * p + 2 + h]) for h in range(2)] for p in range(2)]  # same slab, b=0/1
+            self.g_slabs = [subgroup([2 * q, 2 * q + 1]) for q in range(4)]                          # the slabs of one job
         self.work = (self.g_quad if self.quad else self.pair) if self.world >= 4 else self.pair
+        if self.nh == 2:
+            self.work = self.g_oct
         self.o = backend.optimizers(netG, netD if self.is_gan else None, g_groups, opt.lr_d, opt.beta1)
         self.iteration = 0
         self.dev = next(netG.parameters()).device
@@ -205,16 +258,15 @@ class DistStageTrainer:
             return
         opt.Noise_Amps.append(0)
         amp = 0.0
-        if self.rank == 0 or not self.is_gan:
+        # rank 0 measures the amplitude; in quad / oct mode every rank of the rec pass repeats that forward (they would
+        # only wait for the broadcast otherwise) so that the encoder's spectral-norm u/v AND the noise generator state -
+        # the reparameterisation eps drawn here - stay identical on the ranks that later share the rec pass
+        if self.rank == 0 or not self.is_gan or (self.quad and self.rank < 2 * self.nh):
             with torch.no_grad():
                 rec, _, _ = self.netG(real_zero, opt.Noise_Amps, mode="rec")
                 amp = opt.noise_amp_init * float(torch.sqrt(self.be.mse(real, rec)).item()) / opt.batch_size
         if self.is_gan:
             amp = self._bcast_float(amp, 0)
-            if self.quad and self.rank == 1:
-                # rank 0's calibration forward advanced the encoder's spectral-norm u/v by one power iteration; the other
-                # rank of the rec pass must use the same sigma
-                self.be.advance_sn(self.netG, 1)
         opt.noise_amp = amp
         opt.Noise_Amps[-1] = amp
 
@@ -283,15 +335,43 @@ class DistStageTrainer:
         return out
 
     def _quad_step(self, real, real_zero, noise_init, alpha):
-        """GAN-stage iteration on four ranks: rank q = 2*p + b runs pass p (0 rec, 1 rand) on batch sample b."""
+        """GAN-stage iteration on four ranks: rank q = 2*p + b runs pass p (0 rec, 1 rand) on batch sample b.
+        With row slabs (oct mode, nh = 2): rank = nh*q + h, and job q's upper levels / discriminator work run on slab h."""
+        from .slab import Halo, SlabPlan, slab_rows
         opt, netG, netD, be, o = self.opt, self.netG, self.netD, self.be, self.o
-        p, b = divmod(self.rank, 2)
-        g_pass = self.pair if p == 0 else self.g_rand
-        g_all = self.g_quad
+        nh = self.nh
+        q, h = divmod(self.rank, nh)
+        p, b = divmod(q, 2)
+        if nh == 1:
+            g_pass = self.pair if p == 0 else self.g_rand     # the two samples of this pass
+            g_all = self.g_quad
+        else:
+            g_pass = self.g_samples[p][h]                     # replicated levels: same slab index, the two samples
+            g_all = self.g_oct
+        peer = lambda pp: nh * (2 * pp + b) + h               # same sample and slab in the other pass
         out = {}
         # batch-split BatchNorm inside the pass pair; every noise tensor is drawn for the whole batch (identical generator
-        # state on the two ranks of a pass) and this rank keeps its sample
+        # state on the ranks of a pass) and this rank keeps its sample
         be.set_sync_bn(netG, (lambda t: all_reduce(t, group=g_pass), 2))
+        H = real.shape[-2]
+        r0, r1 = 0, H
+        if nh > 1:
+            nbr = nh * q + (1 - h)
+            g_slab, g_p4 = self.g_slabs[q], self.g_pass4[p]
+            swap = pair_swap(nbr, g_slab)
+            halo = Halo(up=swap if h == 1 else None, down=swap if h == 0 else None)
+            plan = SlabPlan(h, nh, max(opt.vae_levels, opt.scale_idx - self.slab_levels + 1), halo,
+                            lambda t: all_reduce(t, group=g_slab))
+
+            def level_sync(level):  # BatchNorm over both samples and both slabs of the level
+                shape = self._level_shape(level, real.dim() - 2)
+                n = opt.batch_size
+                for d in shape:
+                    n *= int(d)
+                return (lambda t: all_reduce(t, group=g_p4), 2 * nh, n)
+            be.set_slab(netG, netD, plan, level_sync)
+            r0, r1 = slab_rows(H, h, nh)
+        frac = 0.5 * (r1 - r0) / H                            # this rank's share of a mean over (batch, voxels)
         prev_src = netG.noise_source
         draw = prev_src if prev_src is not None else be.noise
 
@@ -300,7 +380,7 @@ class DistStageTrainer:
             return full[b:b + 1].contiguous()
         netG.noise_source = sliced
         try:
-            real_b = real[b:b + 1].contiguous()
+            real_b = real[b:b + 1].narrow(real.dim() - 2, r0, r1 - r0).contiguous()
             if alpha is None:
                 alpha = torch.rand(1, 1) if self.rank == 0 else torch.zeros(1, 1)
             a = alpha.reshape(1).to(self.dev, torch.float32).clone()
@@ -311,9 +391,9 @@ class DistStageTrainer:
             if p == 0:
                 generated, _, _ = netG(real_zero[b:b + 1].contiguous(), opt.Noise_Amps, mode="rec")
                 fake_b = torch.empty_like(real_b)
-                recv(fake_b, src=2 + b)
-                errD_real = be.wgan_mean(netD(real_b), -1.0) * 0.5   # D forward 1 of the reference sequence
-                errD_fake = be.wgan_mean(netD(fake_b), 1.0) * 0.5    # D forward 2
+                recv(fake_b, src=peer(1))
+                errD_real = be.wgan_mean(netD(real_b), -1.0) * frac   # D forward 1 of the reference sequence
+                errD_fake = be.wgan_mean(netD(fake_b), 1.0) * frac    # D forward 2
                 (errD_real + errD_fake).backward()
                 be.advance_sn(netD, 1)                               # forward 3 (gradient penalty) runs on the rand ranks
             else:
@@ -322,9 +402,9 @@ class DistStageTrainer:
                 z = noise_init[b:b + 1].contiguous()
                 fake, _ = netG(z, opt.Noise_Amps, noise_init=z, mode="rand")
                 fake_b = fake.detach().contiguous()
-                send(fake_b, dst=b)
+                send(fake_b, dst=peer(0))
                 be.advance_sn(netD, 2)                               # forwards 1 and 2 run on the rec ranks
-                gp = be.grad_penalty(netD, real_b, fake_b, opt.lambda_grad, a) * 0.5   # D forward 3
+                gp = be.grad_penalty(netD, real_b, fake_b, opt.lambda_grad, a) * frac   # D forward 3
                 gp.backward()
             o.allreduce_D(g_all)
             o.step_D()
@@ -332,16 +412,16 @@ class DistStageTrainer:
             o.zero_G()
             if p == 1:
                 leaf = fake_b.detach().requires_grad_(True)
-                for q in netD.parameters():
-                    q.requires_grad_(False)
-                errG_b = be.wgan_mean(netD(leaf), -1.0) * (0.5 * opt.disc_loss_weight)
+                for w in netD.parameters():
+                    w.requires_grad_(False)
+                errG_b = be.wgan_mean(netD(leaf), -1.0) * (frac * opt.disc_loss_weight)
                 (dfake_b,) = torch.autograd.grad(errG_b, leaf)
-                for q in netD.parameters():
-                    q.requires_grad_(True)
+                for w in netD.parameters():
+                    w.requires_grad_(True)
                 fake.backward(dfake_b)
             else:
                 be.advance_sn(netD, 1)                               # forward 4 (critic term of the G step), new weights
-                rec_loss = be.mse(generated, real_b) * 0.5
+                rec_loss = be.mse(generated, real_b) * frac
                 (opt.rec_weight * rec_loss).backward()
             o.allreduce_G(g_all)
             o.clip_step_G(opt.grad_clip)
@@ -352,7 +432,13 @@ class DistStageTrainer:
         finally:
             netG.noise_source = prev_src
             be.set_sync_bn(netG, None)
+            if nh > 1:
+                be.set_slab(netG, netD, None)
         return out
+
+    def _level_shape(self, level, dims):
+        from . import utils as hu
+        return hu.images.level_shape_3d(level, self.opt) if dims == 3 else hu.images.level_shape_2d(level, self.opt)
 
     def _vae_step(self, real, real_zero):
         """Single generator pass with BatchNorm over the batch: every rank runs the identical step."""
@@ -376,7 +462,7 @@ class DistStageTrainer:
 
     def sync_buffers(self):
         """Average the generator's buffers (BN running stats, SN u/v) over the working ranks at the end of a stage."""
-        n = (4 if self.quad else 2) if (self.is_gan and self.world >= 2) else 1
+        n = self.nwork if (self.is_gan and self.world >= 2) else 1
         if n == 1 or not self.active:
             return
         for b in self.netG.buffers():
@@ -422,7 +508,10 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         # four working ranks from the first stage whose iteration is long enough to pay for the BatchNorm exchanges
         # (~130 small all-reduces per iteration); earlier GAN stages run on two ranks
         quad = world >= 4 and s >= int(os.environ.get("HPVG_QUAD_MIN_STAGE", "5"))
-        trainer = DistStageTrainer(opt, netG, netD, HipBackend(opt), hp_train.generator_param_groups(opt, netG), quad=quad)
+        # eight: two row slabs per job once a level is big enough that halving its convs outweighs ~30 boundary-row swaps
+        oct_ = world >= 8 and s >= int(os.environ.get("HPVG_OCT_MIN_STAGE", "7"))
+        trainer = DistStageTrainer(opt, netG, netD, HipBackend(opt), hp_train.generator_param_groups(opt, netG), quad=quad,
+                                   slabs=2 if oct_ else 1, slab_levels=int(os.environ.get("HPVG_SLAB_LEVELS", "2")))
         built.append((s, trainer, real, real_zero))
 
     class Runner:

@@ -289,7 +289,7 @@ class BNActSync(Function):
     over the whole batch.  dgamma / dbeta are this rank's share (the parameter all-reduce adds the shares up)."""
 
     @staticmethod
-    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu, allreduce, nranks):
+    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu, allreduce, nranks, total=None):
         r = _c(r)
         B, C, T, H, W = geom(r)
         S = T * H * W
@@ -298,7 +298,8 @@ class BNActSync(Function):
         sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
         call("hpvg_bn_sums_f32", ptr(r), ptr(sums), ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
         allreduce(sums)
-        count = float(B) * float(S) * float(nranks)
+        # elements per channel behind the statistics: `total` when the ranks hold unequal shares (row slabs)
+        count = float(total) if total is not None else float(B) * float(S) * float(nranks)
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
         call("hpvg_bn_finalize_f32", ptr(sums), ctypes.c_double(count), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
              float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), C, stream())
@@ -328,7 +329,7 @@ class BNActSync(Function):
         call("hpvg_bn_act_bwd_apply_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              1 if ctx.lrelu else 0, ptr(gsum), float(1.0 / ctx.count), ptr(dr), B, C, ctypes.c_long(S), stream())
         loc32 = local.to(torch.float32)
-        return dr, loc32[:, 1].contiguous(), loc32[:, 0].contiguous(), None, None, None, None, None, None, None
+        return dr, loc32[:, 1].contiguous(), loc32[:, 0].contiguous(), None, None, None, None, None, None, None, None
 
 
 class AffineAct(Function):

@@ -285,10 +285,12 @@ def num_body(P):
 
 
 def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True,
-                      sample_init=None):
+                      sample_init=None, level_fn=None):
     """GeneratorHPVAEGAN.forward (networks_3d.py:367-406).  `noises` is an iterator yielding the N(0,1) draws in
     reference order (reparameterisation eps first, then one tensor per noisy level), or a callable(shape) -> tensor.
-    sample_init = (start_index, tensor): the refinement restarts from that level's tensor (generation path)."""
+    sample_init = (start_index, tensor): the refinement restarts from that level's tensor (generation path).
+    level_fn(idx, inp, up, f) -> x, optional: wraps the evaluation f(inp, up) of refinement level idx+1 (the multi-GPU
+    tests cut the level into row slabs there); None = f(inp, up)."""
     def draw(shape):
         return noises(tuple(shape)) if callable(noises) else next(noises)
 
@@ -310,7 +312,9 @@ def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='ran
         up = resize_linear_ac(x, level_shape(idx + 1, opt, dims))
         inject = mode == 'rand' and (dims == 2 or opt.vae_levels <= idx + 1)
         inp = up + draw(up.shape) * noise_amp[idx + 1] if inject else up
-        x = torch.tanh(_stack7(inp, P, 'body.%d' % idx, opt.num_layer) + up)
+        def f(i_, u_, idx=idx):
+            return torch.tanh(_stack7(i_, P, 'body.%d' % idx, opt.num_layer) + u_)
+        x = f(inp, up) if level_fn is None else level_fn(idx, inp, up, f)
     if noise_init is None:
         return x, vae_out, (mu, logvar)
     return x, vae_out

@@ -53,8 +53,8 @@ def _worker(rank, world, port, fname, outdir, quad=False):
     opt.Z_init_size = list(rec["noise_init"].shape)
     tr = multigpu.DistStageTrainer(opt, netG, netD, multigpu.HipBackend(opt), hp_train.generator_param_groups(opt, netG), quad=quad)
     noises = rec["noises"]
-    if quad:  # rank 0: calibration eps + rec eps, rank 1: rec eps, rand ranks {2, 3}: the level noises
-        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else (noises[1:2] if rank == 1 else noises[2:]), dev)
+    if quad:  # rec ranks {0, 1}: calibration eps + rec eps, rand ranks {2, 3}: the level noises
+        netG.noise_source = NoiseFeed(noises[:2] if rank < 2 else noises[2:], dev)
     else:
         netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], dev)
     out = tr.step(fx["real"].to(dev), fx["real_zero"].to(dev), noise_init=rec["noise_init"].to(dev), alpha=rec["alpha"])
@@ -119,3 +119,105 @@ def test_four_rank_hip_step_matches_reference(fname):
         for k, v in got[0]["G"].items():
             if O.is_param(k):
                 assert torch.equal(v, got[r]["G"][k]), "replicas diverged: " + k
+
+
+def _slab_worker(rank, world, port, fname, outdir):
+    """Both ranks evaluate generator pass + MSE backward and D(real) + gradient penalty backward twice with the gfx950
+    kernels: on the whole image, then on their row slab (halo swaps, BatchNorm sums and level re-assembly over the two
+    ranks); the slab results must be the rows / the rank-summed gradients of the whole-image results."""
+    import copy
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import NoiseFeed, hip_opt, load_golden
+    from hp_vae_gan_amd import multigpu
+    from hp_vae_gan_amd.modules import networks_2d, networks_3d
+    from hp_vae_gan_amd.slab import Halo, SlabPlan, slab_rows
+    fx = load_golden(fname)
+    dims, s = fx["dims"], fx["scale_idx"]
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], dims, s, dev)
+    nets = networks_3d if dims == 3 else networks_2d
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(s):
+        netG.init_next_stage()
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    netD = getattr(nets, opt.discriminator)(opt)
+    netD.load_state_dict(fx["D_init"])
+    netD.to(dev)
+    amps = list(fx["iters"][0]["noise_amps"])
+    rec = fx["iters"][0]
+    be = multigpu.HipBackend(opt)
+    real = fx["real"].to(dev)
+    z = rec["noise_init"].to(dev)
+    alpha = rec["alpha"].reshape(1).to(dev, torch.float32)
+    H = real.shape[-2]
+    r0, r1 = slab_rows(H, rank, 2)
+    state = (copy.deepcopy(netG.state_dict()), copy.deepcopy(netD.state_dict()))
+
+    def run(slab):
+        netG.load_state_dict(state[0])
+        netD.load_state_dict(state[1])
+        netG.zero_grad()
+        netD.zero_grad()
+        netG.noise_source = NoiseFeed(rec["noises"][2:], dev)
+        rows = (r0, r1) if slab else (0, H)
+        frac = (rows[1] - rows[0]) / H
+        real_s = real.narrow(real.dim() - 2, rows[0], rows[1] - rows[0]).contiguous()
+        fake, _ = netG(z, amps, noise_init=z, mode="rand")
+        (be.mse(fake, real_s) * frac).backward()
+        fake_d = fake.detach().contiguous()
+        errD = be.wgan_mean(netD(real_s), -1.0) * frac + be.grad_penalty(netD, real_s, fake_d, opt.lambda_grad, alpha) * frac
+        errD.backward()
+        gG = {k: p.grad.detach().clone() for k, p in netG.named_parameters() if p.grad is not None}
+        gD = {k: p.grad.detach().clone() for k, p in netD.named_parameters() if p.grad is not None}
+        return fake_d, errD.detach().clone(), gG, gD
+
+    whole = run(False)
+    swap = multigpu.pair_swap(1 - rank)
+    plan = SlabPlan(rank, 2, max(opt.vae_levels, s - 1), Halo(up=swap if rank == 1 else None, down=swap if rank == 0 else None),
+                    multigpu.all_reduce)
+
+    def level_sync(level):
+        from hp_vae_gan_amd import utils as hu
+        size = hu.images.level_shape_3d(level, opt) if dims == 3 else hu.images.level_shape_2d(level, opt)
+        n = opt.batch_size
+        for d in size:
+            n *= int(d)
+        return (multigpu.all_reduce, 2, n)
+    be.set_slab(netG, netD, plan, level_sync)
+    part = run(True)
+    be.set_slab(netG, netD, None)
+    be.set_sync_bn(netG, None)
+    errD = part[1].clone()
+    multigpu.all_reduce(errD)
+    for g in (part[2], part[3]):
+        for k in g:
+            multigpu.all_reduce(g[k])
+    torch.cuda.synchronize()
+    torch.save({"fake_whole": whole[0][..., r0:r1, :].cpu(), "fake_slab": part[0].cpu(), "errD": (whole[1].cpu(), errD.cpu()),
+                "gG": ({k: v.cpu() for k, v in whole[2].items()}, {k: v.cpu() for k, v in part[2].items()}),
+                "gD": ({k: v.cpu() for k, v in whole[3].items()}, {k: v.cpu() for k, v in part[3].items()})},
+               os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step2d_gan_s2.pt"])
+def test_two_rank_row_slabs_match_whole_image(fname):
+    """slab.py with the real kernels (the 8-rank oct mode cannot be rehearsed on a one-GPU box: at most 6 processes):
+    generator pass, discriminator, first- and second-order backward on two row slabs == the whole image."""
+    from helpers import assert_close, bn_bias_atol
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_slab_worker, args=(2, _free_port(), fname, d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(2)]
+    for r in range(2):
+        assert_close(got[r]["fake_slab"], got[r]["fake_whole"], 1e-3, "%s.rank%d.fake" % (fname, r))
+        assert_close(got[r]["errD"][1], got[r]["errD"][0], 1e-3, "%s.rank%d.errD" % (fname, r))
+        for which in ("gG", "gD"):
+            whole, part = got[r][which]
+            assert set(whole) == set(part)
+            for k in whole:
+                assert_close(part[k], whole[k], 1e-3, "%s.rank%d.%s.%s" % (fname, r, which, k), atol=bn_bias_atol(k, whole))

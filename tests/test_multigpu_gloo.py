@@ -44,16 +44,56 @@ class OracleNet(nn.Module):
             else:
                 self.register_buffer(name, v.clone())
         self.noise_source = None
+        self.halo = None    # D: slab.Halo while the discriminator runs on row slabs
+        self.slab = None    # G: (slab.SlabPlan, level_sync, backend) while the upper levels run on row slabs
 
     def P(self):
         return {k: getattr(self, k.replace(".", "__")) for k in self.keys}
 
     def forward(self, x, noise_amp=None, noise_init=None, sample_init=None, mode="rand"):
+        O = self.O
         if self.kind == "D":
-            return self.O.discriminator_forward(x, self.P(), self.opt)
+            if self.halo is None:
+                return O.discriminator_forward(x, self.P(), self.opt)
+            with _halo_convs(O, self.halo):
+                return O.discriminator_forward(x, self.P(), self.opt)
         src = self.noise_source
-        return self.O.generator_forward(self.P(), self.opt, self.dims, x, noise_amp, noise_init=noise_init, mode=mode,
-                                        noises=lambda shape: src(torch.empty(shape)))
+        level_fn = None
+        if self.slab is not None:
+            plan, level_sync, be = self.slab
+            nbody = O.num_body(self.P())
+
+            def level_fn(idx, inp, up, f):
+                if not plan.covers(idx + 1):
+                    return f(inp, up)
+                H = up.shape[-2]
+                whole_batch_sync = be._sync
+                be.set_sync_bn(None, level_sync(idx + 1))
+                try:
+                    with _halo_convs(O, plan.halo):
+                        y = f(plan.cut(inp), plan.cut(up))
+                finally:
+                    be.set_sync_bn(None, whole_batch_sync)
+                return plan.gather(y, H) if idx + 1 < nbody else y
+        return O.generator_forward(self.P(), self.opt, self.dims, x, noise_amp, noise_init=noise_init, mode=mode,
+                                   noises=lambda shape: src(torch.empty(shape)), level_fn=level_fn)
+
+
+class _halo_convs:
+    """While active, every oracle convolution runs on a row slab with the neighbour's boundary rows (slab.conv_with_halo
+    around the oracle's own conv)."""
+
+    def __init__(self, O, halo):
+        self.O, self.halo = O, halo
+
+    def __enter__(self):
+        from hp_vae_gan_amd.slab import conv_with_halo
+        O, halo = self.O, self.halo
+        self.plain = plain = O.conv
+        O.conv = lambda x, w, b=None: conv_with_halo(x, halo, lambda xe: plain(xe, w, b))
+
+    def __exit__(self, *exc):
+        self.O.conv = self.plain
 
 
 class TorchBackend:
@@ -61,6 +101,7 @@ class TorchBackend:
         self.opt = opt
         from oracle import hpvg_oracle as O
         self.O = O
+        self._sync = None
 
     def mse(self, a, b):
         return self.O.mse(a, b)
@@ -93,12 +134,14 @@ class TorchBackend:
         """Batch-split BatchNorm for the oracle-backed stand-in: the oracle's batch_norm_train with the per-channel sums
         exchanged through a differentiable all-reduce (test infrastructure; the product path is ops.BNActSync)."""
         O = self.O
+        self._sync = sync
         if not hasattr(O, "_bn_whole_batch"):
             O._bn_whole_batch = O.batch_norm_train
         if sync is None:
             O.batch_norm_train = O._bn_whole_batch
             return
-        allreduce, nranks = sync
+        allreduce, nranks = sync[0], sync[1]
+        total = sync[2] if len(sync) > 2 else None
 
         class Sum(torch.autograd.Function):
             @staticmethod
@@ -116,7 +159,7 @@ class TorchBackend:
         def bn(x, gamma, beta, running_mean=None, running_var=None):
             dimsr = [0] + list(range(2, x.dim()))
             shape = (1, -1) + (1,) * (x.dim() - 2)
-            n = (x.numel() // x.shape[1]) * nranks
+            n = total if total is not None else (x.numel() // x.shape[1]) * nranks
             xd = x.double()
             mean = Sum.apply(xd.sum(dim=dimsr)) / n
             var = Sum.apply(((xd - mean.view(shape)) ** 2).sum(dim=dimsr)) / n
@@ -127,6 +170,11 @@ class TorchBackend:
                     running_var.mul_(1 - O.BN_MOMENTUM).add_(O.BN_MOMENTUM * var.detach().float() * (n / max(n - 1, 1)))
             return y
         O.batch_norm_train = bn
+
+    def set_slab(self, netG, netD, plan, level_sync=None):
+        netG.slab = (plan, level_sync, self) if plan is not None else None
+        if netD is not None:
+            netD.halo = plan.halo if plan is not None else None
 
     def optimizers(self, netG, netD, g_groups, lr_d, beta1):
         class _O:
@@ -166,7 +214,7 @@ def _groups(opt, netG):
     return out
 
 
-def _worker(rank, world, port, fname, outdir, quad=False):
+def _worker(rank, world, port, fname, outdir, quad=False, slabs=1, slab_levels=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -182,13 +230,15 @@ def _worker(rank, world, port, fname, outdir, quad=False):
     netG = OracleNet(fx["G_init"], opt, dims, "G")
     netD = OracleNet(fx["D_init"], opt, dims, "D") if fx["D_init"] is not None else None
     opt.Z_init_size = list(fx["iters"][0]["noise_init"].shape)
-    tr = multigpu.DistStageTrainer(opt, netG, netD, TorchBackend(opt), _groups(opt, netG), quad=quad)
+    tr = multigpu.DistStageTrainer(opt, netG, netD, TorchBackend(opt), _groups(opt, netG), quad=quad, slabs=slabs,
+                                   slab_levels=slab_levels)
+    assert tr.nh == slabs and tr.quad == bool(quad)
     rec = fx["iters"][0]
     gan = netD is not None
     noises = rec["noises"]
     if gan and quad:
-        # rank 0 also runs the calibration pass (first eps); rec ranks {0, 1} draw the rec eps, rand ranks the level noises
-        netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else (noises[1:2] if rank == 1 else noises[2:]), "cpu")
+        # every rec rank repeats the calibration pass (first eps) and draws the rec eps; rand ranks draw the level noises
+        netG.noise_source = NoiseFeed(noises[:2] if rank < 2 * slabs else noises[2:], "cpu")
     elif gan:
         # reference draw order: [calibration eps], rec eps, then the level noises of the rand pass
         netG.noise_source = NoiseFeed(noises[:2] if rank == 0 else noises[2:], "cpu")
@@ -198,7 +248,7 @@ def _worker(rank, world, port, fname, outdir, quad=False):
     alpha = rec["alpha"] if rec["alpha"] is not None else None
     out = tr.step(fx["real"], fx["real_zero"], noise_init=rec["noise_init"], alpha=alpha)
     tr.sync_buffers()
-    if rank < (4 if quad else 2):
+    if rank < (4 * slabs if quad else 2):
         torch.save({"out": {k: v for k, v in out.items()}, "amps": opt.Noise_Amps,
                     "G": {k: v.detach().clone() for k, v in netG.P().items()},
                     "D": {k: v.detach().clone() for k, v in netD.P().items()} if gan else None},
@@ -278,6 +328,38 @@ def test_quad_step_matches_single_process(fname, world):
             if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
                 assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
     for r in range(1, 4):
+        for k in got[0]["G"]:
+            if O.is_param(k):
+                assert torch.equal(got[0]["G"][k], got[r]["G"][k]), k
+        for k in got[0]["D"]:
+            if O.is_param(k):
+                assert torch.equal(got[0]["D"][k], got[r]["D"][k]), k
+
+
+@pytest.mark.parametrize("fname,slab_levels", [("step3d_gan_s3.pt", 2), ("step2d_gan_s2.pt", 1), ("step3d_gan_s2_all.pt", 1)])
+def test_oct_step_matches_single_process(fname, slab_levels):
+    """Eight working ranks: the four (pass, sample) jobs on two row slabs each - boundary-row swaps on every conv of the
+    slabbed generator levels and of the discriminator (first- and second-order backward), BatchNorm over samples and
+    slabs, level outputs re-assembled between slabbed levels, lower levels replicated - same losses, parameters and D u/v
+    buffers as the single process."""
+    from helpers import assert_close
+    from oracle import hpvg_oracle as O
+    fx, want, PG, PD, amps = _single_process(fname)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(8, _free_port(), fname, d, True, 2, slab_levels), nprocs=8, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(8)]
+    lr = fx["opt"]["lr_g"]
+    for r in range(8):
+        assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
+            assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
+        for k, v in PG.items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        for k, v in PD.items():
+            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    for r in range(1, 8):
         for k in got[0]["G"]:
             if O.is_param(k):
                 assert torch.equal(got[0]["G"][k], got[r]["G"][k]), k
