@@ -362,3 +362,51 @@ class GeneratorSG(nn.Module):
                 x_prev = block(self._zero_pad(up))
             x_prev_out = ops.Add.apply(x_prev, up)
         return ops.TanhRes.apply(x_prev_out, None)
+
+
+class GeneratorCSG(nn.Module):
+    """The baselines script's default generator (reference: networks_3d.py:213-269; `--generator GeneratorCSG`,
+    train_video_baselines.py:232): ONE head block (noise -> nfc features) and ONE tail conv + tanh around a growing list
+    of stages, each num_layer VALID conv blocks on a volume padded by num_layer voxels per side; the nfc-channel
+    features - not images - are upsampled from stage to stage and added back without a tanh.  `noise_source` as in
+    GeneratorHPVAEGAN.  State-dict keys: head.*, body.k.blockI.*, tail.0.{weight,bias} (the reference's tail is
+    Sequential(Conv3d, Tanh))."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        N = int(opt.nfc)
+        self.pad = opt.num_layer
+        self.head = ConvBlock(3, opt.nc_im, N, opt.ker_size, 0, 1)
+        self.body = nn.ModuleList([])
+        first = nn.Sequential()
+        for i in range(opt.num_layer):
+            first.add_module('block%d' % i, ConvBlock(3, N, N, opt.ker_size, 0, 1))
+        self.body.append(first)
+        self.tail = nn.Sequential(Conv(3, N, opt.nc_im, opt.ker_size, 0, 1))
+        self.apply(weights_init)
+        self.noise_source = None
+
+    def init_next_stage(self):
+        self.body.append(copy.deepcopy(self.body[-1]))
+
+    @staticmethod
+    def _zero_pad(x, p):
+        return torch.nn.functional.pad(x, (p,) * 6)
+
+    def forward(self, noise_init, noise_amp, mode='rand'):
+        p = self.pad
+        x_prev_out = self.body[0](self._zero_pad(self.head(self._zero_pad(noise_init, 1)), p))
+        for idx, block in enumerate(self.body[1:], 1):
+            size = hp_utils.images.level_shape_3d(idx, self.opt)
+            up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
+            if mode == 'rand':
+                big = tuple(s + 2 * p for s in size)
+                ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
+                noise = self.noise_source(ref) if self.noise_source is not None else hp_utils.generate_noise(ref=ref)
+                _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, noise, float(noise_amp[idx]))
+                x_prev = block(up2_noisy)
+            else:
+                x_prev = block(self._zero_pad(up, p))
+            x_prev_out = ops.Add.apply(x_prev, up)
+        return ops.TanhRes.apply(self.tail(self._zero_pad(x_prev_out, 1)), None)

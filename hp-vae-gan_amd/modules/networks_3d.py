@@ -4,7 +4,7 @@ from . import _nets
 from .. import ops
 
 __all__ = ['ConvBlock3D', 'ConvBlock3DSN', 'FeatureExtractor', 'Encode3DVAE', 'WDiscriminator3D', 'GeneratorHPVAEGAN',
-           'GeneratorSG', 'weights_init', 'reparameterize']
+           'GeneratorSG', 'GeneratorCSG', 'weights_init', 'reparameterize']
 
 weights_init = _nets.weights_init
 
@@ -50,3 +50,7 @@ class GeneratorHPVAEGAN(_nets.GeneratorHPVAEGAN):
 
 class GeneratorSG(_nets.GeneratorSG):
     """SinGAN-3D baseline (BASELINE config 5; reference: networks_3d.py:272-322)."""
+
+
+class GeneratorCSG(_nets.GeneratorCSG):
+    """SinGAN-3D baseline with shared head / tail, the default of train_video_baselines.py (reference: networks_3d.py:213-269)."""

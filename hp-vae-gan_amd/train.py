@@ -218,6 +218,11 @@ class BaselineStageTrainer:
                 p.requires_grad = False
         blocks = list(netG.body[-opt.train_depth:])
         groups = [(b.parameters(), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, b in enumerate(blocks)]
+        # GeneratorCSG: the shared head trains only while every stage still does, the tail always (train_video_baselines.py:67-72)
+        if hasattr(netG, 'head') and opt.scale_idx - opt.train_depth < 0:
+            groups.append((netG.head.parameters(), opt.lr_g * (opt.lr_scale ** opt.scale_idx)))
+        if hasattr(netG, 'tail'):
+            groups.append((netG.tail.parameters(), opt.lr_g))
         self.arenaD = hp_optim.ParamArena(self.netD)
         self.optimizerD = hp_optim.FlatAdam(self.arenaD, [(self.netD.parameters(), opt.lr_d)], betas=(opt.beta1, 0.999))
         self.arenaG = hp_optim.ParamArena(netG)

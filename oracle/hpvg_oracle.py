@@ -217,20 +217,72 @@ def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None
     return torch.tanh(x)
 
 
+def generator_csg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None):
+    """GeneratorCSG.forward (networks_3d.py:246-269): head block on the noise, then per stage num_layer VALID conv blocks
+    on a volume padded by num_layer; the nfc-channel FEATURES (not images) are upsampled between stages and added
+    back without tanh; one tail conv + tanh at the end.  Keys: head.*, body.k.blockI.*, tail.0.{weight,bias}."""
+    nl = opt.num_layer
+    pn, p1 = (nl,) * 6, (1,) * 6
+
+    def stack(x, k):
+        for i in range(nl):
+            x = _bn_block_valid(x, P, 'body.%d.block%d' % (k, i))
+        return x
+
+    x = stack(F.pad(_bn_block_valid(F.pad(noise_init, p1), P, 'head'), pn), 0)
+    k = 1
+    while 'body.%d.block0.conv.weight' % k in P:
+        size = level_shape(k, opt, 3)
+        up = resize_linear_ac(x, size)
+        if mode == 'rand':
+            up2 = resize_linear_ac(x, [s_ + 2 * nl for s_ in size])
+            nz = noises(tuple(up2.shape)) if callable(noises) else next(noises)
+            xp = stack(up2 + nz * noise_amp[k], k)
+        else:
+            xp = stack(F.pad(up, pn), k)
+        x = xp + up
+        k += 1
+    return torch.tanh(conv_valid(F.pad(x, p1), P['tail.0.weight'], P['tail.0.bias']))
+
+
+def baseline_g_groups(PG, opt, scale_idx):
+    """[(key prefix, lr)] of the baseline generator optimizer (train_video_baselines.py:55-73): the last train_depth
+    body blocks with lr_g * lr_scale^(distance from the newest); `head` (if the generator has one) only while every
+    block is still trained, at lr_g * lr_scale^scale_idx; `tail` (if any) at lr_g."""
+    nb = 0
+    while any(k.startswith('body.%d.' % nb) for k in PG):
+        nb += 1
+    blocks = list(range(nb))[-opt.train_depth:]
+    groups = [('body.%d.' % kb, opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, kb in enumerate(blocks)]
+    if any(k.startswith('head.') for k in PG) and scale_idx - opt.train_depth < 0:
+        groups.append(('head.', opt.lr_g * (opt.lr_scale ** scale_idx)))
+    if any(k.startswith('tail.') for k in PG):
+        groups.append(('tail.', opt.lr_g))
+    return groups
+
+
 def baseline_train_step(PG, PD, opt, scale_idx, real, Z_init, noise_init, noises, alphas, noise_amps, adam_g, adam_d):
-    """One iteration of the baseline train() (train_video_baselines.py:93-173) with all random draws injected."""
+    """One iteration of the baseline train() (train_video_baselines.py:93-173) with all random draws injected.
+    The generator is GeneratorCSG when the state dict has a top-level `head`, else GeneratorSG."""
     out = {}
-    nb = num_body(PG)
-    trained = ['body.%d.' % k for k in range(nb)][-opt.train_depth:]
+    csg = 'head.conv.weight' in PG
+    gen_forward = generator_csg_forward if csg else generator_sg_forward
+    groups = baseline_g_groups(PG, opt, scale_idx)
+    # blocks outside the optimizer are frozen (requires_grad False); head / tail always keep requires_grad (only `body`
+    # blocks are frozen, train_video_baselines.py:55-58), so they receive gradients even when head is not optimised
+    nb = 0
+    while any(k.startswith('body.%d.' % nb) for k in PG):
+        nb += 1
+    trained = ['body.%d.' % k for k in range(nb)][-opt.train_depth:] + ['head.', 'tail.']
     gparams = {k: v for k, v in PG.items() if is_param(k) and any(k.startswith(t) for t in trained)}
     dparams = {k: v for k, v in PD.items() if is_param(k)}
     for j in range(opt.Dsteps):
         errD_real = -discriminator_forward(real, PD, opt).mean()
         if j == opt.Dsteps - 1:
-            fake = generator_sg_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
+            fake = gen_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
         else:
             with torch.no_grad():
-                fake = generator_sg_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
+                fake = gen_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
         errD_fake = discriminator_forward(fake.detach(), PD, opt).mean()
         gp = gradient_penalty(PD, opt, real, fake, opt.lambda_grad, alphas[j])
         dgrads = torch.autograd.grad(errD_real + errD_fake + gp, list(dparams.values()), allow_unused=True)
@@ -242,18 +294,16 @@ def baseline_train_step(PG, PD, opt, scale_idx, real, Z_init, noise_init, noises
     errG = -discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
     total = errG
     if opt.alpha > 0:
-        generated = generator_sg_forward(PG, opt, Z_init, noise_amps, 'rec', None)
+        generated = gen_forward(PG, opt, Z_init, noise_amps, 'rec', None)
         rec_loss = opt.alpha * mse(generated, real)
         total = total + rec_loss
         out['rec_loss'] = rec_loss.detach()
     keys = list(gparams.keys())
     grads = torch.autograd.grad(total, [gparams[k] for k in keys], allow_unused=True)
     out['gradsG'] = {k: (g.clone() if g is not None else None) for k, g in zip(keys, grads)}
-    blocks = list(range(nb))[-opt.train_depth:]
-    for i, kb in enumerate(blocks):
-        lr = opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))
+    for prefix, lr in groups:
         for k, g in zip(keys, grads):
-            if k.startswith('body.%d.' % kb) and g is not None:
+            if k.startswith(prefix) and g is not None:
                 for _ in range(opt.Gsteps):
                     with torch.no_grad():
                         adam_step(gparams[k], g, adam_g.setdefault(k, {}), lr, opt.beta1)

@@ -256,13 +256,13 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
     return fx
 
 
-def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed):
-    """train_video_baselines.py:93-173 driven around the reference's GeneratorSG / WDiscriminator3D."""
+def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, generator='GeneratorSG'):
+    """train_video_baselines.py:93-173 driven around the reference's GeneratorSG / GeneratorCSG + WDiscriminator3D."""
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
     images.adjust_scales2image(opt.img_size, opt)
     opt.stop_scale_time = opt.stop_scale
-    netG = n3.GeneratorSG(opt)
+    netG = getattr(n3, generator)(opt)
     for _ in range(scale_idx):
         netG.init_next_stage()
     perturb(netG, gen)
@@ -273,8 +273,13 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed):
         for p in block.parameters():
             p.requires_grad = False
     blocks = netG.body[-opt.train_depth:]
-    optimizerG = optim.Adam([{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))}
-                             for i, b in enumerate(blocks)], lr=opt.lr_g, betas=(opt.beta1, 0.999))
+    parameter_list = [{"params": b.parameters(), "lr": opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))}
+                      for i, b in enumerate(blocks)]
+    if hasattr(netG, 'head') and scale_idx - opt.train_depth < 0:        # train_video_baselines.py:67-71
+        parameter_list += [{"params": netG.head.parameters(), "lr": opt.lr_g * (opt.lr_scale ** scale_idx)}]
+    if hasattr(netG, 'tail'):
+        parameter_list += [{"params": netG.tail.parameters(), "lr": opt.lr_g}]
+    optimizerG = optim.Adam(parameter_list, lr=opt.lr_g, betas=(opt.beta1, 0.999))
 
     def shape(i):
         w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
@@ -476,6 +481,9 @@ def main():
         'step2d_gan_s2.pt': lambda: run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=1), 2, 2, 2, seed=103),
         'step2d_vae_s1.pt': lambda: with_kink_margin(lambda sd: run_stage_steps(images, n2, losses, mutils, make_opt(vae_levels=3), 2, 1, 1, seed=sd), 104, 2e-5),
         'baseline3d_s2.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=2, Gsteps=1, alpha=10.0, train_depth=1), 2, 1, seed=105),
+        # the baselines script's DEFAULT generator (64-channel features between stages, head/tail trained along)
+        'baseline3d_csg_s2.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=3), 2, 1, seed=109,
+                                                           generator='GeneratorCSG'),
         'sample3d_s3.pt': lambda: run_sampling(images, n3, make_opt(vae_levels=2), 3, 3, seed=106),
         # non-default training depth: the last two blocks train (no detach between them, scaled learning rates), and
         # --train-all with every level open (train_video.py:74-86, networks_3d.py:391-392)

@@ -84,16 +84,18 @@ def test_smoke_entry():
     run_smoke()
 
 
-def test_baseline_singan_step_matches_reference():
-    """BASELINE config 5: GeneratorSG + BaselineStageTrainer (HIP) against the reference-generated fixture."""
+@pytest.mark.parametrize("fname,generator", [("baseline3d_s2.pt", "GeneratorSG"), ("baseline3d_csg_s2.pt", "GeneratorCSG")])
+def test_baseline_singan_step_matches_reference(fname, generator):
+    """BASELINE config 5 (GeneratorSG) and the baselines script's default GeneratorCSG: BaselineStageTrainer (HIP)
+    against the reference-generated fixtures."""
     from helpers import NoiseFeed, hip_opt
     from hp_vae_gan_amd import train as hp_train
     from hp_vae_gan_amd.modules import networks_3d
-    fx = load_golden("baseline3d_s2.pt")
+    fx = load_golden(fname)
     s = fx["scale_idx"]
     dev = "cuda"
     opt = hip_opt(fx["opt"], 3, s, dev)
-    netG = networks_3d.GeneratorSG(opt)
+    netG = getattr(networks_3d, generator)(opt)
     for _ in range(s):
         netG.init_next_stage()
     assert list(netG.state_dict().keys()) == list(fx["G_init"].keys())

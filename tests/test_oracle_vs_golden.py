@@ -222,9 +222,11 @@ def test_c_restatement_of_conv_matches():
         assert_close(y, want, 1e-5, "conv_direct.c")
 
 
-def test_baseline_singan_step():
-    """SinGAN-3D baseline (BASELINE config 5): oracle step vs the reference-generated fixture."""
-    fx = load_golden("baseline3d_s2.pt")
+@pytest.mark.parametrize("fname", ["baseline3d_s2.pt", "baseline3d_csg_s2.pt"])
+def test_baseline_singan_step(fname):
+    """SinGAN-3D baselines (BASELINE config 5: GeneratorSG; and train_video_baselines.py's default GeneratorCSG with its
+    head / tail optimizer groups): oracle step vs the reference-generated fixture."""
+    fx = load_golden(fname)
     opt = opt_from(fx["opt"])
     O.adjust_scales2image(opt.img_size, opt)
     opt.stop_scale_time = opt.stop_scale
@@ -233,7 +235,8 @@ def test_baseline_singan_step():
     rec = fx["iters"][0]
     amps = list(fx["noise_amps_init"])
     amps.append(0)
-    z = O.generator_sg_forward(PG, opt, fx["Z_init"], amps, "rec", None)
+    fwd = O.generator_csg_forward if "csg" in fname else O.generator_sg_forward
+    z = fwd(PG, opt, fx["Z_init"], amps, "rec", None)
     amps[-1] = opt.noise_amp_init * float(torch.sqrt(O.mse(fx["real"], z))) / opt.batch_size
     assert amps == pytest.approx(rec["noise_amps"], rel=1e-5)
     out = O.baseline_train_step(PG, PD, opt, s, fx["real"], fx["Z_init"], rec["noise_init"], iter(rec["noises"]),
