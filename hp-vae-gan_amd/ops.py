@@ -79,14 +79,34 @@ def _kt(w_shape):
 
 
 # ------------------------------------------------------------------------------------------ raw launches
+_pack_cache = {}
+
+
+def weights_changed():
+    """Forget every packed weight: called by whatever rewrites parameters behind torch's back (the Adam kernel writes
+    through raw pointers, so no version counter moves) and around hipGraph capture."""
+    _pack_cache.clear()
+
+
 def pack_weight(w, flip):
-    """Natural [Co][Ci][taps] weight -> MFMA fragment order (forward, or backward-data when flip)."""
+    """Natural [Co][Ci][taps] weight -> MFMA fragment order (forward, or backward-data when flip).
+
+    The same weight is packed for several launches between two optimizer steps (rec and rand generator passes; forward,
+    backward-data and the double-backward convs of one discriminator evaluation): the packed copy is kept until
+    `weights_changed()`, keyed by the weight's storage and validated by its version counter.  The entry holds a
+    detached alias of the weight, so the allocator cannot hand the address to another tensor while the entry lives."""
+    w = _c(w)
+    key = (w.data_ptr(), bool(flip), tuple(w.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+        return hit[2]
     Co, Ci = w.shape[0], w.shape[1]
     KT = _kt(w.shape)
     cin_k, cout_k = (Co, Ci) if flip else (Ci, Co)
     n = call("hpvg_conv_wpack_floats", cin_k, cout_k, KT)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    call("hpvg_conv_pack_weight_f32", ptr(_c(w)), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, stream())
+    call("hpvg_conv_pack_weight_f32", ptr(w), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, stream())
+    _pack_cache[key] = (w._version, w.detach(), wp)
     return wp
 
 
@@ -613,6 +633,7 @@ def clip_scale_(flat_grad, sq, max_norm, coef_out=None):
 
 
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, step_dev=None):
+    weights_changed()
     call("hpvg_adam_step_f32", ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_long(p.numel()), float(lr), float(beta1), float(beta2),
          float(eps), int(step), ptr(step_dev), stream())
 

@@ -8,6 +8,7 @@ yielding `real` (stage 0) or `(real, real_zero)` device tensors."""
 
 import torch
 
+from . import ops
 from . import optim as hp_optim
 from . import utils
 from .modules import networks_2d, networks_3d
@@ -103,8 +104,10 @@ class StageTrainer:
         torch.cuda.current_stream().wait_stream(side)
         it = self.iteration
         self._graph = torch.cuda.CUDAGraph()
+        ops.weights_changed()  # packed weights made outside the capture must not be baked into it, nor its buffers reused after
         with torch.cuda.graph(self._graph):
             self._g_out = self._step_eager(self._g_real, self._g_rz)
+        ops.weights_changed()
         self.iteration = it  # capture records the launches, it does not execute the iteration
         return self
 

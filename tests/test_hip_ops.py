@@ -390,3 +390,26 @@ def test_golden_gradient_penalty(ops):
 def test_cpu_tensor_fails_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.Conv.apply(torch.zeros(1, 3, 4, 4), torch.zeros(8, 3, 3, 3), None, False)
+
+
+def test_packed_weight_cache_follows_the_weight(ops):
+    """ops.pack_weight keeps the MFMA-order copy of a weight between optimizer steps: a second launch with the same
+    weight reuses it, an in-place torch update (version counter), an Adam step (raw kernel -> weights_changed) and a new
+    tensor at a recycled address all get a fresh pack."""
+    x = _rand(1, 64, 3, 6, 7, seed=1).to(DEV)
+    w = _rand(64, 64, 3, 3, 3, seed=2, scale=0.05).to(DEV)
+    ops.weights_changed()
+    y0 = ops.conv_fwd_raw(x, w, None)
+    wp0 = ops.pack_weight(w, False)
+    assert ops.pack_weight(w, False) is wp0 and ops.pack_weight(w, True) is not wp0
+    assert_close(y0, O.conv(x.cpu(), w.cpu()), RTOL, "cache.first")
+    w.mul_(2.0)                                                     # torch in-place: version moves
+    assert ops.pack_weight(w, False) is not wp0
+    assert_close(ops.conv_fwd_raw(x, w, None), O.conv(x.cpu(), w.cpu()), RTOL, "cache.after-inplace")
+    g, m, v = torch.ones_like(w), torch.zeros_like(w), torch.zeros_like(w)
+    ops.adam_step_(w.view(-1), g.view(-1), m.view(-1), v.view(-1), 0.05, 0.5, 0.999, 1e-8, 1)   # raw kernel: no version bump
+    assert_close(ops.conv_fwd_raw(x, w, None), O.conv(x.cpu(), w.cpu()), RTOL, "cache.after-adam")
+    addr = w.data_ptr()
+    del w, wp0
+    w2 = _rand(64, 64, 3, 3, 3, seed=3, scale=0.05).to(DEV)         # may or may not land on the old address
+    assert_close(ops.conv_fwd_raw(x, w2, None), O.conv(x.cpu(), w2.cpu()), RTOL, "cache.new-tensor(%s)" % (w2.data_ptr() == addr))
