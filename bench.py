@@ -199,9 +199,10 @@ def main():
     ap.add_argument("--stages", type=str, default="0-9", help="pyramid stages in a step, e.g. 0-9 or 9")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stages", type=str, default="0-5")
-    ap.add_argument("--graph-stages", type=str, default="none",
-                    help="stages whose iteration is replayed as a hipGraph, e.g. 0-5 (measured: no gain - the small stages "
-                         "are bound by the serial chain of ~10 us kernels on the GPU, not by host launches); default none")
+    ap.add_argument("--graph-stages", type=str, default="0-8",
+                    help="stages whose iteration is captured once and replayed as a hipGraph (single-GPU path; the stage "
+                         "holding the roofline kernel always stays eager so that its launches can be bracketed by events); "
+                         "'none' = every stage eager.  Measured r01: +52 % at stage 0, +8 % at stage 3, +2 % at stage 7")
     ap.add_argument("--config", choices=["video", "image"], default="video",
                     help="video = BASELINE configs[2] (the metric's config, default); image = configs[1] (2-D path)")
     args = ap.parse_args()

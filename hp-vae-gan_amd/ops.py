@@ -40,6 +40,17 @@ def set_kernel_timer(t):
     _kernel_timer = t
 
 
+_ws_pinned = []
+
+
+def pin_workspaces():
+    """From now on a scratch buffer that is outgrown is kept alive instead of freed: a captured hipGraph holds the raw
+    address of the buffer that was current at capture time, and replays it long after a larger stage replaced it."""
+    if not _ws_pinned:
+        _ws_pinned.append(None)
+    _ws_pinned.extend(_ws_cache.values())
+
+
 def workspace(nbytes, device):
     """Stream-ordered scratch buffer shared by all ops on `device` (grown on demand)."""
     key = (device.type, device.index)
@@ -47,6 +58,8 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        if _ws_pinned:
+            _ws_pinned.append(buf)
     return buf
 
 

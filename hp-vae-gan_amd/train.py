@@ -97,6 +97,7 @@ class StageTrainer:
         self._g_real = real.clone()
         self._g_rz = self._g_real if real_zero is real else real_zero.clone()
         self._graph_alpha = True
+        ops.pin_workspaces()  # the graph bakes in scratch addresses: they must outlive later (larger) stages' buffers
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -120,6 +121,7 @@ class StageTrainer:
             if real_zero.data_ptr() != self._g_rz.data_ptr() and self._g_rz is not self._g_real:
                 self._g_rz.copy_(real_zero)
             self._graph.replay()
+            ops.weights_changed()  # the replayed Adam kernels moved the weights without passing through python
             self.iteration += 1
             self.last = self._g_out
             return self._g_out
@@ -187,7 +189,8 @@ def train(opt, netG, data, netD=None, niter=None):
         opt.fps, opt.td, opt.fps_index = fps, td, fps_index
     trainer = StageTrainer(opt, netG, netD)
     iterator = iter(data)
-    for _ in range(opt.niter if niter is None else niter):
+    n = opt.niter if niter is None else niter
+    while trainer.iteration < n:
         try:
             item = next(iterator)
         except StopIteration:
@@ -199,6 +202,12 @@ def train(opt, netG, data, netD=None, niter=None):
             real = item
             real_zero = real
         trainer.step(real, real_zero)
+        # after two eager iterations (noise-amplitude calibration done, every workspace at its final size) the iteration
+        # is captured once and replayed as a hipGraph: the host leaves the critical path (opt.hip_graph = False: stay
+        # eager).  Capturing runs one more real iteration on this batch first (side-stream warm-up), which counts.
+        if (trainer.iteration == 2 and n - trainer.iteration >= 2 and getattr(opt, 'hip_graph', True)
+                and getattr(trainer, '_graph', None) is None and real.is_cuda):
+            trainer.enable_graph(real, real_zero)
     return trainer
 
 

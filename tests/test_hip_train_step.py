@@ -182,6 +182,11 @@ def test_graph_replay_equals_eager(fname):
         torch.manual_seed(7)
         b_tr.step(real, rz)
         b_tr.enable_graph(real, rz)          # runs one warm-up iteration (eager, side stream) + capture (no execution)
+        # the graph bakes in the scratch buffer's address: a later, larger request must not free that buffer
+        from hp_vae_gan_amd import ops as hp_ops
+        baked = hp_ops.workspace(1, real.device)
+        grown = hp_ops.workspace(baked.numel() + (1 << 20), real.device)
+        assert grown is not baked and any(b is baked for b in hp_ops._ws_pinned)
         for _ in range(2):
             b_tr.step(real, rz)              # replays
         torch.cuda.synchronize()
@@ -241,3 +246,47 @@ def test_several_iterations_track_the_oracle(fname, iters):
     worst = max(float((sd[k].float().cpu() - v.detach().float()).abs().max()) for k, v in PG.items() if O.is_param(k))
     assert worst <= 3 * lr, "post-training G parameters drifted by %.3e (> 3 lr*N = %.3e)" % (worst, 3 * lr)
     assert trainer.opt.Noise_Amps == pytest.approx(amps, rel=1e-4)
+
+
+def test_train_loop_captures_the_iteration_after_two_eager_steps():
+    """train.train(): the reference-shaped stage loop (train_video.py:98-109 data cycling, :111-202 step) - two eager
+    iterations, then hipGraph replays fed from the data iterator through the static input buffers; opt.hip_graph=False
+    keeps it eager.  Both runs stay finite and keep training (the reconstruction loss of the fixed clip goes down)."""
+    from helpers import hip_opt
+    from hp_vae_gan_amd import train as hp_train
+    from hp_vae_gan_amd.modules import networks_3d
+    fx = load_golden("step3d_gan_s3.pt")
+    dev = "cuda"
+    s = fx["scale_idx"]
+    real, rz = fx["real"].to(dev), fx["real_zero"].to(dev)
+    data = [(real, rz), (real.flip(-1).contiguous(), rz.flip(-1).contiguous())]   # a 2-item "loader", cycled
+    for use_graph in (True, False):
+        opt = hip_opt(fx["opt"], 3, s, dev)
+        opt.hip_graph = use_graph
+        opt.niter = 12
+        netG = networks_3d.GeneratorHPVAEGAN(opt)
+        for _ in range(s):
+            netG.init_next_stage()
+        netG.load_state_dict(fx["G_init"])
+        netG.to(dev)
+        netD = networks_3d.WDiscriminator3D(opt)
+        netD.load_state_dict(fx["D_init"])
+        netD.to(dev)
+        opt.Noise_Amps = list(fx["noise_amps_init"])
+        torch.manual_seed(3)
+        tr = hp_train.train(opt, netG, data, netD=netD, niter=1)
+        first = float(tr.last["rec_loss"])
+        opt.scale_idx = s
+        torch.manual_seed(3)
+        # a fresh trainer on the already-stepped nets would re-calibrate; run the long loop on a fresh copy instead
+        netG.load_state_dict(fx["G_init"])
+        netD.load_state_dict(fx["D_init"])
+        opt.Noise_Amps = list(fx["noise_amps_init"])
+        tr = hp_train.train(opt, netG, data, netD=netD)
+        torch.cuda.synchronize()
+        assert tr.iteration == 12
+        assert (getattr(tr, "_graph", None) is not None) == use_graph
+        last = float(tr.last["rec_loss"])
+        assert last == last and last < first, (use_graph, first, last)
+        for k, v in netG.state_dict().items():
+            assert torch.isfinite(v.float()).all(), k
