@@ -450,33 +450,92 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
                                                               float* __restrict__ v, float* __restrict__ sigma_out,
                                                               float* __restrict__ inv_sigma_out, int Co, int K, int do_iter,
                                                               float eps, float* __restrict__ wv_ws) {
+  // The whole power iteration is one dependent chain on ONE workgroup (442 KB of weights): what it costs is memory
+  // latency, so the two matrix-vector products read W as float4 with every thread's loads independent of each other.
   __shared__ double sh[16];
   __shared__ float su[1024];
+  __shared__ float4 part[1024];
+  __shared__ float4 sv4[1024];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int K4 = K >> 2;
+  const bool vec = (K & 3) == 0 && K4 <= 1024 && (((size_t)w | (size_t)v) & 15) == 0;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
   for (int o = tid; o < Co; o += 1024) su[o] = u[o];
   __syncthreads();
   if (do_iter) {
     // v = normalize(W^T u)
     double nrm = 0.0;
-    for (int k = tid; k < K; k += 1024) {
-      float acc = 0.f;
-      for (int o = 0; o < Co; ++o) acc += w[(long)o * K + k] * su[o];
-      v[k] = acc;
-      nrm += (double)acc * acc;
+    if (vec) {
+      // thread = (float4 column c, row slice s): S row slices share a column and meet in LDS
+      const int S = K4 <= 512 ? min(1024 / K4, 8) : 1;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid < S * K4) {
+        const int c = tid % K4, s0 = tid / K4;
+#pragma unroll 8
+        for (int o = s0; o < Co; o += S) {
+          const float4 x = w4[(long)o * K4 + c];
+          const float uo = su[o];
+          acc.x += x.x * uo; acc.y += x.y * uo; acc.z += x.z * uo; acc.w += x.w * uo;
+        }
+      }
+      part[tid] = acc;
+      __syncthreads();
+      if (tid < K4) {
+        float4 t = part[tid];
+        for (int s1 = 1; s1 < S; ++s1) {
+          const float4 q = part[s1 * K4 + tid];
+          t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+        }
+        sv4[tid] = t;
+        nrm = (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
+      }
+    } else {
+      for (int k = tid; k < K; k += 1024) {
+        float acc = 0.f;
+        for (int o = 0; o < Co; ++o) acc += w[(long)o * K + k] * su[o];
+        v[k] = acc;
+        nrm += (double)acc * acc;
+      }
     }
     const double tot = block1024_sum(nrm, sh);
     const float den = fmaxf((float)sqrt(tot), eps);
     __syncthreads();
-    for (int k = tid; k < K; k += 1024) v[k] = v[k] / den;
+    if (vec) {
+      if (tid < K4) {
+        float4 t = sv4[tid];
+        t.x /= den; t.y /= den; t.z /= den; t.w /= den;
+        sv4[tid] = t;
+        reinterpret_cast<float4*>(v)[tid] = t;
+      }
+    } else {
+      for (int k = tid; k < K; k += 1024) v[k] = v[k] / den;
+    }
+    __syncthreads();
+  } else if (vec) {
+    if (tid < K4) sv4[tid] = reinterpret_cast<const float4*>(v)[tid];
     __syncthreads();
   }
   // wv = W v  (one wave per row, rows strided by 16)
-  for (int o = wave; o < Co; o += 16) {
-    float acc = 0.f;
-    for (int k = lane; k < K; k += 64) acc += w[(long)o * K + k] * v[k];
-    acc = hpvg_wave_sum(acc);
-    if (lane == 0) wv_ws[o] = acc;
+  if (vec) {
+    for (int o = wave; o < Co; o += 16) {
+      float acc = 0.f;
+#pragma unroll 7
+      for (int c = lane; c < K4; c += 64) {
+        const float4 x = w4[(long)o * K4 + c];
+        const float4 y = sv4[c];
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      acc = hpvg_wave_sum(acc);
+      if (lane == 0) wv_ws[o] = acc;
+    }
+  } else {
+    for (int o = wave; o < Co; o += 16) {
+      float acc = 0.f;
+      for (int k = lane; k < K; k += 64) acc += w[(long)o * K + k] * v[k];
+      acc = hpvg_wave_sum(acc);
+      if (lane == 0) wv_ws[o] = acc;
+    }
   }
   __syncthreads();
   if (do_iter) {
@@ -508,14 +567,41 @@ __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ 
                                                        int K) {
   __shared__ double sh[16];
   const long n = (long)Co * K;
+  const bool vec = (K & 3) == 0 && (((size_t)dweff | (size_t)worig | (size_t)v | (size_t)dworig) & 15) == 0;
   double acc = 0.0;
-  for (long i = threadIdx.x; i < n; i += 1024) acc += (double)dweff[i] * worig[i];
+  if (vec) {  // one workgroup, latency bound: float4 and independent loads
+    const float4* a4 = reinterpret_cast<const float4*>(dweff);
+    const float4* b4 = reinterpret_cast<const float4*>(worig);
+    const long n4 = n >> 2;
+#pragma unroll 4
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+      const float4 a = a4[i], b = b4[i];
+      acc += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+    }
+  } else {
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)dweff[i] * worig[i];
+  }
   const double dot = block1024_sum(acc, sh);
   const float sg = sigma[0];
   const float coef = (float)(dot / ((double)sg * sg));
-  for (long i = threadIdx.x; i < n; i += 1024) {
-    const int o = (int)(i / K), k = (int)(i - (long)o * K);
-    dworig[i] = dweff[i] / sg - coef * u[o] * v[k];
+  if (vec) {
+    const float4* a4 = reinterpret_cast<const float4*>(dweff);
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    float4* o4 = reinterpret_cast<float4*>(dworig);
+    const int K4 = K >> 2;
+    const long n4 = n >> 2;
+#pragma unroll 4
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+      const int o = (int)(i / K4), c = (int)(i - (long)o * K4);
+      const float4 a = a4[i], y = v4[c];
+      const float cu = coef * u[o];
+      o4[i] = make_float4(a.x / sg - cu * y.x, a.y / sg - cu * y.y, a.z / sg - cu * y.z, a.w / sg - cu * y.w);
+    }
+  } else {
+    for (long i = threadIdx.x; i < n; i += 1024) {
+      const int o = (int)(i / K), k = (int)(i - (long)o * K);
+      dworig[i] = dweff[i] / sg - coef * u[o] * v[k];
+    }
   }
 }
 
