@@ -16,6 +16,7 @@ def calc_gradient_penalty(netD, real_data, fake_data, LAMBDA, device, alpha=None
     interpolates.requires_grad_(True)
     disc_interpolates = netD(interpolates)
     ones = torch.ones_like(disc_interpolates)
-    gradients = torch.autograd.grad(outputs=disc_interpolates, inputs=interpolates, grad_outputs=ones,
-                                    create_graph=True, retain_graph=True, only_inputs=True)[0]
+    with ops.inputs_only():  # d/dx_hat only: no weight / bias gradients in this pass (they come from the double backward)
+        gradients = torch.autograd.grad(outputs=disc_interpolates, inputs=interpolates, grad_outputs=ones,
+                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
     return ops.GradPenalty.apply(gradients, float(LAMBDA))

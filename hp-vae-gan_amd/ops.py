@@ -187,6 +187,21 @@ def _reduce_ws(device):
     return workspace(n, device), n
 
 
+class inputs_only:
+    """with ops.inputs_only(): a backward pass that is known to want gradients w.r.t. activations only
+    (torch.autograd.grad(D(x_hat), x_hat) of the gradient penalty).  A Python autograd Function cannot see which of its
+    inputs the running graph task needs - ctx.needs_input_grad only says "requires grad" - so without this every conv
+    of the critic would also launch its weight- and bias-gradient kernels there, for results the engine throws away."""
+    active = False
+
+    def __enter__(self):
+        self.prev = inputs_only.active
+        inputs_only.active = True
+
+    def __exit__(self, *exc):
+        inputs_only.active = self.prev
+
+
 # ------------------------------------------------------------------------------------------ conv family
 class LReLUMaskMul(Function):
     """dy * (h > 0 ? 1 : 0.2) - leaky_relu_backward on the activated tensor (reference: networks_3d.py:21)."""
@@ -234,9 +249,10 @@ class Conv(Function):
         dy = _c(dy)
         if ctx.act:
             dy = LReLUMaskMul.apply(dy, y)
+        params = not inputs_only.active
         dx = ConvBwdData.apply(dy, w) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeight.apply(dy, x, w.shape) if ctx.needs_input_grad[1] else None
-        db = ChannelSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = ConvBwdWeight.apply(dy, x, w.shape) if (ctx.needs_input_grad[1] and params) else None
+        db = ChannelSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2] and params) else None
         return dx, dw, db, None
 
 
