@@ -490,12 +490,13 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
   const double tot = hpvg_block_sum_d(acc, sh);
   if (threadIdx.x == 0) part[(long)c * nsplit + k] = tot;
 }
-__global__ void channel_sum_finish_kernel(const double* __restrict__ part, int nsplit, int C, float* __restrict__ out) {
+__global__ void channel_sum_finish_kernel(const double* __restrict__ part, int nsplit, int C, float* __restrict__ out,
+                                          int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
   for (int k = 0; k < nsplit; ++k) s += part[(long)c * nsplit + k];
-  out[c] = (float)s;
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 struct WPlan {
@@ -685,9 +686,10 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   return hpvg_launch_status();
 }
 
-// out[c] = sum over batch and all spatial positions of x[b][c][...]  (conv bias gradient); ws: C*64 doubles
+// out[c] (+)= sum over batch and all spatial positions of x[b][c][...]  (conv bias gradient); ws: C*64 doubles
 size_t hpvg_channel_sum_ws_bytes(int C) { return (size_t)C * 64 * sizeof(double); }
-int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, size_t ws_bytes, int B, int C, long S,
+                         void* stream) {
   if (!x || !out || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
   if (ws_bytes < hpvg_channel_sum_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
   long want = (1024 + C - 1) / C;
@@ -702,7 +704,8 @@ int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, 
     case 2: hipLaunchKernelGGL(channel_sum_partial_kernel<2>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
     default: hipLaunchKernelGGL(channel_sum_partial_kernel<1>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
   }
-  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, out);
+  hipLaunchKernelGGL(channel_sum_finish_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, out,
+                     accumulate);
   return hpvg_launch_status();
 }
 

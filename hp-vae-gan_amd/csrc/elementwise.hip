@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsplit, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+                                       float* __restrict__ dbeta, float* __restrict__ sums, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -214,8 +214,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nspl
     s1 += part[((long)c * nsplit + k) * 2 + 0];
     s2 += part[((long)c * nsplit + k) * 2 + 1];
   }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
+  dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+  dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
   sums[2 * c] = (float)s1;
   sums[2 * c + 1] = (float)s2;
 }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ dweff, const float* __restrict__ worig,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        const float* __restrict__ sigma, float* __restrict__ dworig, int Co,
-                                                       int K) {
+                                                       int K, int accumulate) {
   __shared__ double sh[16];
   const long n = (long)Co * K;
   const bool vec = (K & 3) == 0 && (((size_t)dweff | (size_t)worig | (size_t)v | (size_t)dworig) & 15) == 0;
@@ -595,12 +595,18 @@ __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ 
       const int o = (int)(i / K4), c = (int)(i - (long)o * K4);
       const float4 a = a4[i], y = v4[c];
       const float cu = coef * u[o];
-      o4[i] = make_float4(a.x / sg - cu * y.x, a.y / sg - cu * y.y, a.z / sg - cu * y.z, a.w / sg - cu * y.w);
+      float4 t = make_float4(a.x / sg - cu * y.x, a.y / sg - cu * y.y, a.z / sg - cu * y.z, a.w / sg - cu * y.w);
+      if (accumulate) {
+        const float4 p = o4[i];
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      o4[i] = t;
     }
   } else {
     for (long i = threadIdx.x; i < n; i += 1024) {
       const int o = (int)(i / K), k = (int)(i - (long)o * K);
-      dworig[i] = dweff[i] / sg - coef * u[o] * v[k];
+      const float t = dweff[i] / sg - coef * u[o] * v[k];
+      dworig[i] = accumulate ? dworig[i] + t : t;
     }
   }
 }
@@ -741,8 +747,8 @@ int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, 
 
 // dr, dgamma, dbeta of  h = lrelu?(BN_train(r))  given dh
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
-                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B,
-                        int C, long S, void* stream) {
+                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
+                        size_t ws_bytes, int B, int C, long S, void* stream) {
   if (!dh || !r || !mean || !invstd || !scale || !shift || !dr || !dgamma || !dbeta || !ws) return HPVG_ERR_ARG;
   if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
   const int ns = bn_nsplit(B, C, S);
@@ -756,7 +762,7 @@ int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, cons
     else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
-                     sums);
+                     sums, accumulate);
   int nbx = hpvg_cdiv(S, 256 * 4);
   if (nbx > 1024) nbx = 1024;
   hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
@@ -897,9 +903,10 @@ int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, flo
   return hpvg_launch_status();
 }
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
-                    int Co, int K, void* stream) {
+                    int accumulate, int Co, int K, void* stream) {
   if (!dweff || !worig || !u || !v || !sigma || !dworig || Co < 1 || K < 1) return HPVG_ERR_ARG;
-  hipLaunchKernelGGL(sn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dweff, worig, u, v, sigma, dworig, Co, K);
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dweff, worig, u, v, sigma, dworig, Co, K,
+                     accumulate);
   return hpvg_launch_status();
 }
 

@@ -36,11 +36,11 @@ _SIGS = {
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],
     "hpvg_channel_sum_ws_bytes": [I],
-    "hpvg_channel_sum_f32": [P, P, P, Z, I, I, L, P],
+    "hpvg_channel_sum_f32": [P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_ws_bytes": [I],
     "hpvg_bn_train_stats_f32": [P, P, P, P, P, F, F, P, P, P, P, P, Z, I, I, L, P],
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
-    "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, P, P, P, P, Z, I, I, L, P],
+    "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, P, P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_sums_f32": [P, P, P, Z, I, I, L, P],
     "hpvg_bn_finalize_f32": [P, D, P, P, P, P, F, F, P, P, P, P, I, P],
     "hpvg_bn_act_bwd_sums_f32": [P, P, P, P, P, P, I, P, P, Z, I, I, L, P],
@@ -67,7 +67,7 @@ _SIGS = {
     "hpvg_upsample_linear_ac_bwd_f32": [P, P, L, I, I, I, I, I, I, P],
     "hpvg_sn_power_iter_f32": [P, P, P, P, P, I, I, I, F, P, Z, P],
     "hpvg_div_scalar_f32": [P, P, P, L, P],
-    "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, I, P],
+    "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
     "hpvg_counter_inc_i32": [P, P],

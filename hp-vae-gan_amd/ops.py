@@ -5,6 +5,7 @@ hand-written gfx950 kernel in libhpvg.so.  The convolution family {Conv, ConvBwd
 LReLUMaskMul} is closed under differentiation (each backward is expressed with the other Functions), which is
 what the WGAN-GP double backward through the discriminator needs (reference: modules/utils.py:14-18)."""
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -153,7 +154,28 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     return y
 
 
-def conv_bwd_weight_raw(dy, x, w_shape):
+_DIRECT_GRAD = os.environ.get("HPVG_DIRECT_GRAD", "1") != "0"
+
+
+def grad_slot(p):
+    """The gradient buffer of parameter `p` when a backward kernel may add its result straight into it, else None.
+
+    autograd would take the returned gradient and run `p.grad += it` as one more (4.7 us) kernel per parameter and
+    contribution - ~210 per GAN iteration.  The kernels that produce parameter gradients (weight-gradient reduce, channel
+    sum, BatchNorm finalize, spectral-norm backward) can do that addition themselves: when `p` is a leaf that already has
+    a dense fp32 `.grad` (the trainers' ParamArena gives every parameter one, zeroed per step) and no graph is being
+    recorded, the Function adds into `p.grad` and returns None for that input.  Same numbers as AccumulateGrad;
+    tensor hooks on `p` do not fire for it (HPVG_DIRECT_GRAD=0 restores plain autograd accumulation)."""
+    if not _DIRECT_GRAD or p is None or torch.is_grad_enabled() or not (p.is_leaf and p.requires_grad):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or g.device != p.device or not g.is_contiguous():
+        return None
+    return g
+
+
+def conv_bwd_weight_raw(dy, x, w_shape, into=None):
+    """dw of the conv; `into` (a gradient buffer of the weight's shape): add the result into it and return None."""
     dy = _c(dy)
     x = _c(x)
     B, Co, T, H, W = geom(dy)
@@ -163,19 +185,28 @@ def conv_bwd_weight_raw(dy, x, w_shape):
         raise RuntimeError("conv_bwd_weight: channel mismatch")
     nbytes = call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT)
     ws = workspace(nbytes, dy.device)
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
-    call("hpvg_conv_bwd_weight_f32", ptr(dy), ptr(x), None, None, 0, ptr(dw), 0, ptr(ws), ctypes.c_size_t(ws.numel()),
-         B, Ci, Co, T, H, W, KT, stream())
-    return dw
+    dw = into if into is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    call("hpvg_conv_bwd_weight_f32", ptr(dy), ptr(x), None, None, 0, ptr(dw), 1 if into is not None else 0, ptr(ws),
+         ctypes.c_size_t(ws.numel()), B, Ci, Co, T, H, W, KT, stream())
+    return None if into is not None else dw
 
 
-def channel_sum_raw(dy):
+def channel_sum_raw(dy, into=None):
     dy = _c(dy)
     B, C, T, H, W = geom(dy)
-    out = torch.empty(C, dtype=torch.float32, device=dy.device)
+    out = into if into is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
     ws = workspace(call("hpvg_channel_sum_ws_bytes", C), dy.device)
-    call("hpvg_channel_sum_f32", ptr(dy), ptr(out), ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(T * H * W), stream())
-    return out
+    call("hpvg_channel_sum_f32", ptr(dy), ptr(out), 1 if into is not None else 0, ptr(ws), ctypes.c_size_t(ws.numel()), B, C,
+         ctypes.c_long(T * H * W), stream())
+    return None if into is not None else out
+
+
+def _weight_grad(dy, x, w):
+    """dw for Conv / ConvBwdData backward: added straight into w.grad when allowed (returns None), else a Function."""
+    slot = grad_slot(w)
+    if slot is not None:
+        return conv_bwd_weight_raw(dy, x, w.shape, into=slot)
+    return ConvBwdWeight.apply(dy, x, w.shape)
 
 
 def _scalar_out(device):
@@ -238,21 +269,24 @@ class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
         y = conv_fwd_raw(x, w, b, out_lrelu=act)
-        ctx.save_for_backward(x, w, y if act else None)
+        ctx.save_for_backward(x, w, y if act else None, b)
         ctx.act = act
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         dy = _c(dy)
         if ctx.act:
             dy = LReLUMaskMul.apply(dy, y)
         params = not inputs_only.active
         dx = ConvBwdData.apply(dy, w) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeight.apply(dy, x, w.shape) if (ctx.needs_input_grad[1] and params) else None
-        db = ChannelSum.apply(dy) if (ctx.has_bias and ctx.needs_input_grad[2] and params) else None
+        dw = _weight_grad(dy, x, w) if (ctx.needs_input_grad[1] and params) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and params:
+            slot = grad_slot(b)
+            db = channel_sum_raw(dy, into=slot) if slot is not None else ChannelSum.apply(dy)
         return dx, dw, db, None
 
 
@@ -269,7 +303,7 @@ class ConvBwdData(Function):
         dy, w = ctx.saved_tensors
         g = _c(g)
         ddy = Conv.apply(g, w, None, False) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeight.apply(dy, g, w.shape) if ctx.needs_input_grad[1] else None
+        dw = _weight_grad(dy, g, w) if ctx.needs_input_grad[1] else None
         return ddy, dw
 
 
@@ -309,25 +343,29 @@ class BNAct(Function):
         h = torch.empty_like(r)
         call("hpvg_affine_act_f32", ptr(r), ptr(stats[2]), ptr(stats[3]), ptr(h), 1 if lrelu else 0, B, C,
              ctypes.c_long(S), stream())
-        ctx.save_for_backward(r, stats)
+        ctx.save_for_backward(r, stats, gamma, beta)
         ctx.lrelu = lrelu
         return h
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dh):
-        r, stats = ctx.saved_tensors
+        r, stats, gamma, beta = ctx.saved_tensors
         dh = _c(dh)
         B, C, T, H, W = geom(r)
         S = T * H * W
         dev = r.device
         dr = torch.empty_like(r)
-        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        sg, sb = grad_slot(gamma), grad_slot(beta)
+        direct = sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        dgb = (sg, sb) if direct else torch.empty(2, C, dtype=torch.float32, device=dev)
         nws = call("hpvg_bn_ws_bytes", C)
         ws = workspace(nws, dev)
         call("hpvg_bn_act_bwd_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-             1 if ctx.lrelu else 0, ptr(dr), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), ctypes.c_size_t(ws.numel()), B, C,
-             ctypes.c_long(S), stream())
+             1 if ctx.lrelu else 0, ptr(dr), ptr(dgb[0]), ptr(dgb[1]), 1 if direct else 0, ptr(ws), ctypes.c_size_t(ws.numel()),
+             B, C, ctypes.c_long(S), stream())
+        if direct:
+            return dr, None, None, None, None, None, None, None
         return dr, dgb[0], dgb[1], None, None, None, None, None
 
 
@@ -426,9 +464,11 @@ class SpectralNormWeight(Function):
         dw = _c(dw)
         Co = w_orig.shape[0]
         K = w_orig.numel() // Co
-        out = torch.empty_like(w_orig)
-        call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(out), Co, K, stream())
-        return out, None, None, None, None
+        slot = grad_slot(w_orig)
+        out = slot if slot is not None else torch.empty_like(w_orig)
+        call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(out), 1 if slot is not None else 0, Co, K,
+             stream())
+        return (None if slot is not None else out), None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ generator glue

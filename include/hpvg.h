@@ -52,9 +52,11 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
                              float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
                              int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
-/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient */
+/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient.  accumulate != 0: out[c] += (the caller passes the parameter's
+ * gradient buffer, which removes autograd's AccumulateGrad add kernel) */
 size_t hpvg_channel_sum_ws_bytes(int C);
-int hpvg_channel_sum_f32(const float* x, float* out, void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
+int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, size_t ws_bytes, int B, int C, long S,
+                         void* stream);
 
 /* ---- BatchNorm3d/2d, train mode on every forward (networks_3d.py:54), eps 1e-5, momentum 0.1 */
 size_t hpvg_bn_ws_bytes(int C);
@@ -64,10 +66,11 @@ int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* bet
 /* y = LeakyReLU_opt(scale[c]*x + shift[c]) (BN apply + nn.LeakyReLU(0.2), networks_3d.py:21,54-56) */
 int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int lrelu, int B, int C, long S,
                         void* stream);
-/* backward of h = LeakyReLU_opt(BN_train(r)): dr, dgamma, dbeta (native_batch_norm_backward + leaky_relu_backward) */
+/* backward of h = LeakyReLU_opt(BN_train(r)): dr, dgamma, dbeta (native_batch_norm_backward + leaky_relu_backward);
+ * accumulate != 0: dgamma / dbeta += */
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
-                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int B,
-                        int C, long S, void* stream);
+                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
+                        size_t ws_bytes, int B, int C, long S, void* stream);
 /* BatchNorm with the batch split over ranks (one process per GPU): the rank-local per-channel sums are double pairs the
  * caller all-reduces (RCCL) between the two halves; statistics, running buffers and dr then follow from the global sums.
  * Same arithmetic as the single-GPU entry points above (which are sums + finalize / sums + apply in one call). */
@@ -126,8 +129,9 @@ int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, flo
                            float eps, void* ws, size_t ws_bytes, void* stream);
 /* out = x / s[0]: weight = weight_orig / sigma (torch SpectralNorm.compute_weight) */
 int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream);
+/* dworig (+)= dweff/sigma - (sum(dweff .* worig)/sigma^2) u v^T  (backward of weight_orig -> weight) */
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
-                    int Co, int K, void* stream);
+                    int accumulate, int Co, int K, void* stream);
 
 /* ---- optimizer: clip_grad_norm_ (train_video.py:201) and optim.Adam (train_video.py:55,88) over flat arenas */
 int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, float* coef_out /*nullable, 2 floats*/,
