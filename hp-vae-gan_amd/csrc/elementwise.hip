@@ -449,7 +449,7 @@ __device__ __forceinline__ double block1024_sum(double v, double* sh) {
 __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ w, float* __restrict__ u,
                                                               float* __restrict__ v, float* __restrict__ sigma_out,
                                                               float* __restrict__ inv_sigma_out, int Co, int K, int do_iter,
-                                                              float eps, float* __restrict__ wv_ws) {
+                                                              float eps, float* __restrict__ wv_ws, float* __restrict__ uv_copy) {
   // The whole power iteration is one dependent chain on ONE workgroup (442 KB of weights): what it costs is memory
   // latency, so the two matrix-vector products read W as float4 with every thread's loads independent of each other.
   __shared__ double sh[16];
@@ -557,41 +557,63 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
     sigma_out[0] = (float)sig;
     inv_sigma_out[0] = (float)(1.0 / sig);
   }
+  if (uv_copy) {  // the (u, v) this sigma belongs to, for the backward (later forwards overwrite the buffers)
+    for (int o = tid; o < Co; o += 1024) uv_copy[o] = su[o];
+    if (vec) {
+      for (int c = tid; c < K4; c += 1024) {
+        const float4 t = sv4[c];
+        float* d = uv_copy + Co + 4 * c;
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+      }
+    } else {
+      for (int k = tid; k < K; k += 1024) uv_copy[Co + k] = v[k];
+    }
+  }
 }
 
 // backward of W = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
-//   dW_orig[o][k] = dW[o][k]/sigma - (sum(dW .* W_orig)/sigma^2) * u[o] v[k]
-__global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ dweff, const float* __restrict__ worig,
-                                                       const float* __restrict__ u, const float* __restrict__ v,
-                                                       const float* __restrict__ sigma, float* __restrict__ dworig, int Co,
-                                                       int K, int accumulate) {
-  __shared__ double sh[16];
-  const long n = (long)Co * K;
-  const bool vec = (K & 3) == 0 && (((size_t)dweff | (size_t)worig | (size_t)v | (size_t)dworig) & 15) == 0;
+//   dW_orig[o][k] (+)= dW[o][k]/sigma - (sum(dW .* W_orig)/sigma^2) * u[o] v[k]
+// Two launches over G workgroups (4096 elements each): partial dots -> ws (doubles), then every workgroup sums the G
+// partials in the same fixed order and applies its chunk.  (One workgroup for everything took 40-70 us on 442 KB.)
+constexpr int SN_CHUNK = 4096;
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dweff, const float* __restrict__ worig, long n,
+                                                          int vec, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const long lo = (long)blockIdx.x * SN_CHUNK;
+  const long hi = lo + SN_CHUNK < n ? lo + SN_CHUNK : n;
   double acc = 0.0;
-  if (vec) {  // one workgroup, latency bound: float4 and independent loads
+  if (vec) {
     const float4* a4 = reinterpret_cast<const float4*>(dweff);
     const float4* b4 = reinterpret_cast<const float4*>(worig);
-    const long n4 = n >> 2;
 #pragma unroll 4
-    for (long i = threadIdx.x; i < n4; i += 1024) {
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256) {
       const float4 a = a4[i], b = b4[i];
       acc += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
     }
   } else {
-    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)dweff[i] * worig[i];
+    for (long i = lo + threadIdx.x; i < hi; i += 256) acc += (double)dweff[i] * worig[i];
   }
-  const double dot = block1024_sum(acc, sh);
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dweff, const float* __restrict__ u,
+                                                            const float* __restrict__ v, const float* __restrict__ sigma,
+                                                            const double* __restrict__ part, int nparts,
+                                                            float* __restrict__ dworig, long n, int K, int vec, int accumulate) {
+  double dot = 0.0;
+  for (int g = 0; g < nparts; ++g) dot += part[g];  // same order in every workgroup
   const float sg = sigma[0];
   const float coef = (float)(dot / ((double)sg * sg));
+  const long lo = (long)blockIdx.x * SN_CHUNK;
+  const long hi = lo + SN_CHUNK < n ? lo + SN_CHUNK : n;
   if (vec) {
     const float4* a4 = reinterpret_cast<const float4*>(dweff);
     const float4* v4 = reinterpret_cast<const float4*>(v);
     float4* o4 = reinterpret_cast<float4*>(dworig);
     const int K4 = K >> 2;
-    const long n4 = n >> 2;
 #pragma unroll 4
-    for (long i = threadIdx.x; i < n4; i += 1024) {
+    for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256) {
       const int o = (int)(i / K4), c = (int)(i - (long)o * K4);
       const float4 a = a4[i], y = v4[c];
       const float cu = coef * u[o];
@@ -603,7 +625,7 @@ __global__ __launch_bounds__(1024) void sn_bwd_kernel(const float* __restrict__ 
       o4[i] = t;
     }
   } else {
-    for (long i = threadIdx.x; i < n; i += 1024) {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
       const int o = (int)(i / K), k = (int)(i - (long)o * K);
       const float t = dweff[i] / sg - coef * u[o] * v[k];
       dworig[i] = accumulate ? dworig[i] + t : t;
@@ -894,18 +916,25 @@ int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti,
 
 // spectral norm: optional power iteration (updates u, v in place), sigma and 1/sigma (device scalars)
 // ws: Co floats
-int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, int Co, int K, int do_iter,
-                           float eps, void* ws, size_t ws_bytes, void* stream) {
+int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, float* uv_copy, int Co, int K,
+                           int do_iter, float eps, void* ws, size_t ws_bytes, void* stream) {
   if (!w || !u || !v || !sigma || !inv_sigma || !ws || Co < 1 || Co > 1024 || K < 1) return HPVG_ERR_ARG;
   if (ws_bytes < (size_t)Co * sizeof(float)) return HPVG_ERR_WORKSPACE;
   hipLaunchKernelGGL(sn_power_iter_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, u, v, sigma, inv_sigma, Co, K, do_iter,
-                     eps, (float*)ws);
+                     eps, (float*)ws, uv_copy);
   return hpvg_launch_status();
 }
+size_t hpvg_sn_bwd_ws_bytes(int Co, int K) { return (size_t)hpvg_cdiv((long)Co * K, SN_CHUNK) * sizeof(double); }
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
-                    int accumulate, int Co, int K, void* stream) {
-  if (!dweff || !worig || !u || !v || !sigma || !dworig || Co < 1 || K < 1) return HPVG_ERR_ARG;
-  hipLaunchKernelGGL(sn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dweff, worig, u, v, sigma, dworig, Co, K,
+                    int accumulate, void* ws, size_t ws_bytes, int Co, int K, void* stream) {
+  if (!dweff || !worig || !u || !v || !sigma || !dworig || !ws || Co < 1 || K < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_sn_bwd_ws_bytes(Co, K)) return HPVG_ERR_WORKSPACE;
+  const long n = (long)Co * K;
+  const int G = (int)hpvg_cdiv(n, SN_CHUNK);
+  const int vec = (K & 3) == 0 && (((size_t)dweff | (size_t)worig | (size_t)v | (size_t)dworig) & 15) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(G), dim3(256), 0, s, dweff, worig, n, vec, (double*)ws);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(G), dim3(256), 0, s, dweff, u, v, sigma, (const double*)ws, G, dworig, n, K, vec,
                      accumulate);
   return hpvg_launch_status();
 }

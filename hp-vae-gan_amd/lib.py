@@ -65,14 +65,15 @@ _SIGS = {
     "hpvg_upsample_linear_ac_f32": [P, P, P, F, P, L, I, I, I, I, I, I, P],
     "hpvg_frames_resize_norm_u8_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "hpvg_upsample_linear_ac_bwd_f32": [P, P, L, I, I, I, I, I, I, P],
-    "hpvg_sn_power_iter_f32": [P, P, P, P, P, I, I, I, F, P, Z, P],
+    "hpvg_sn_power_iter_f32": [P, P, P, P, P, P, I, I, I, F, P, Z, P],
     "hpvg_div_scalar_f32": [P, P, P, L, P],
-    "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, I, I, P],
+    "hpvg_sn_bwd_ws_bytes": [I, I],
+    "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, P, Z, I, I, P],
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
     "hpvg_counter_inc_i32": [P, P],
 }
-_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 
 
 def header_symbols():

@@ -103,6 +103,24 @@ class BatchNorm(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        # train-mode forwards not yet added to the buffer above.  Nothing on the path reads the count (momentum is a
+        # constant), so instead of one int64 add kernel per BatchNorm per forward (~75 launches an iteration) the count
+        # is kept on the host and written to the buffer when somebody asks for it (state_dict / flush_counters).
+        self.pending_batches = 0
+        self.register_state_dict_pre_hook(BatchNorm._flush_hook)
+        self._register_load_state_dict_pre_hook(self._loading_hook)
+
+    @staticmethod
+    def _flush_hook(module, prefix, keep_vars):
+        module.flush_counter()
+
+    def _loading_hook(self, *args):
+        self.pending_batches = 0
+
+    def flush_counter(self):
+        if self.pending_batches:
+            self.num_batches_tracked.add_(self.pending_batches)
+            self.pending_batches = 0
 
     # multi-GPU: (allreduce callable, number of ranks, total count or None) when the batch - and, on row slabs, the
     # image - is split over a process group (multigpu.py sets it on the BatchNorms of a sharded generator pass): the
@@ -111,7 +129,7 @@ class BatchNorm(nn.Module):
 
     def forward(self, r, lrelu=True):
         if self.training:
-            self.num_batches_tracked.add_(1)
+            self.pending_batches += 1
             if self.sync is not None:
                 return ops.BNActSync.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
                                            self.eps, lrelu, self.sync[0], self.sync[1],

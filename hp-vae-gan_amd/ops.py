@@ -449,25 +449,28 @@ class SpectralNormWeight(Function):
         dev = w_orig.device
         sig = torch.empty(2, dtype=torch.float32, device=dev)  # sigma, 1/sigma
         ws = workspace(Co * 4, dev)
-        call("hpvg_sn_power_iter_f32", ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(sig[1:2]), Co, K,
+        # later forwards overwrite the u/v buffers before this call's backward runs: the kernel also writes the (u, v) its
+        # sigma belongs to into `uv` (torch clones them for the same reason); [0, Co) = u, [Co, Co + K) = v
+        uv = torch.empty(Co + K, dtype=torch.float32, device=dev) if w_orig.requires_grad else None
+        call("hpvg_sn_power_iter_f32", ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(sig[1:2]), ptr(uv), Co, K,
              1 if do_iter else 0, float(eps), ptr(ws), ctypes.c_size_t(ws.numel()), stream())
         w = torch.empty_like(w_orig)
         call("hpvg_div_scalar_f32", ptr(w_orig), ptr(sig[0:1]), ptr(w), ctypes.c_long(w.numel()), stream())
-        # later forwards overwrite the u/v buffers before this call's backward runs: keep copies (as torch does)
-        ctx.save_for_backward(w_orig, u.clone(), v.clone(), sig)
+        ctx.save_for_backward(w_orig, uv, sig)
         return w
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dw):
-        w_orig, u, v, sig = ctx.saved_tensors
+        w_orig, uv, sig = ctx.saved_tensors
         dw = _c(dw)
         Co = w_orig.shape[0]
         K = w_orig.numel() // Co
         slot = grad_slot(w_orig)
         out = slot if slot is not None else torch.empty_like(w_orig)
-        call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(u), ptr(v), ptr(sig[0:1]), ptr(out), 1 if slot is not None else 0, Co, K,
-             stream())
+        ws = workspace(call("hpvg_sn_bwd_ws_bytes", Co, K), dw.device)
+        call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(uv[:Co]), ptr(uv[Co:]), ptr(sig[0:1]), ptr(out),
+             1 if slot is not None else 0, ptr(ws), ctypes.c_size_t(ws.numel()), Co, K, stream())
         return (None if slot is not None else out), None, None, None, None
 
 

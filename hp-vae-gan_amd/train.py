@@ -105,10 +105,17 @@ class StageTrainer:
         torch.cuda.current_stream().wait_stream(side)
         it = self.iteration
         self._graph = torch.cuda.CUDAGraph()
+        # host-side state that python advances while it records the iteration: BatchNorm forward counts (replays must add
+        # the same amounts, the capture itself must not count)
+        bns = [m for net in (self.netG, self.netD) if net is not None for m in net.modules() if hasattr(m, 'pending_batches')]
+        before = [m.pending_batches for m in bns]
         ops.weights_changed()  # packed weights made outside the capture must not be baked into it, nor its buffers reused after
         with torch.cuda.graph(self._graph):
             self._g_out = self._step_eager(self._g_real, self._g_rz)
         ops.weights_changed()
+        self._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
+        for m, b in zip(bns, before):
+            m.pending_batches = b
         self.iteration = it  # capture records the launches, it does not execute the iteration
         return self
 
@@ -122,6 +129,8 @@ class StageTrainer:
                 self._g_rz.copy_(real_zero)
             self._graph.replay()
             ops.weights_changed()  # the replayed Adam kernels moved the weights without passing through python
+            for m, d in self._graph_bn:
+                m.pending_batches += d
             self.iteration += 1
             self.last = self._g_out
             return self._g_out

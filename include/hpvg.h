@@ -125,13 +125,14 @@ int hpvg_frames_resize_norm_u8_f32(const unsigned char* src, float* dst, int N, 
                                    int w, int hflip, int quantize, void* stream);
 
 /* ---- spectral norm (nn.utils.spectral_norm, networks_3d.py:63): one power iteration, sigma, 1/sigma; backward through sigma */
-int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, int Co, int K, int do_iter,
-                           float eps, void* ws, size_t ws_bytes, void* stream);
+int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, float* uv_copy, int Co, int K,
+                           int do_iter, float eps, void* ws, size_t ws_bytes, void* stream);
 /* out = x / s[0]: weight = weight_orig / sigma (torch SpectralNorm.compute_weight) */
 int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream);
 /* dworig (+)= dweff/sigma - (sum(dweff .* worig)/sigma^2) u v^T  (backward of weight_orig -> weight) */
+size_t hpvg_sn_bwd_ws_bytes(int Co, int K);
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
-                    int accumulate, int Co, int K, void* stream);
+                    int accumulate, void* ws, size_t ws_bytes, int Co, int K, void* stream);
 
 /* ---- optimizer: clip_grad_norm_ (train_video.py:201) and optim.Adam (train_video.py:55,88) over flat arenas */
 int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, float* coef_out /*nullable, 2 floats*/,
