@@ -144,6 +144,59 @@ __global__ void bn_sum_partials_kernel(const double* __restrict__ part, int nspl
   sums[2 * c + 1] = s2;
 }
 
+// Train-mode BatchNorm apply with the statistics finalize folded in: every workgroup rebuilds ITS channel's (mean, invstd,
+// scale, shift) from the nsplit partial pairs (one wave, fixed shuffle tree: the same bits in every workgroup); the
+// workgroup (x = 0, b = 0) of a channel also publishes them and updates the running statistics.  Saves the finalize launch.
+__global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ part, int nsplit,
+                                                              double count, float eps, float momentum,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                              float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                              float* __restrict__ y, int C, long S, int lrelu) {
+  __shared__ float s_sc, s_sh;
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    double s1 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 0] : 0.0;
+    double s2 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 1] : 0.0;
+    s1 = hpvg_wave_sum_d(s1);
+    s2 = hpvg_wave_sum_d(s2);
+    if (k == 0) {
+      const double mean = s1 / count;
+      double var = s2 / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      const float sc = g * invstd;
+      const float sh = bt - (float)mean * sc;
+      s_sc = sc;
+      s_sh = sh;
+      if (blockIdx.x == 0 && bc == c) {
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        scale_out[c] = sc;
+        shift_out[c] = sh;
+        if (running_mean) {
+          const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float sc = s_sc, sh = s_sh;
+  const float* xp = x + (long)bc * S;
+  float* yp = y + (long)bc * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    float v = xp[i] * sc + sh;
+    if (lrelu) v = hpvg_lrelu(v);
+    yp[i] = v;
+  }
+}
+
 // y = lrelu?(scale[c]*x + shift[c])      grid (blocks over S, B*C)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ y, int C, long S,
@@ -230,6 +283,48 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
   const int c = bc % C;
   const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
   const float m1 = sums[2 * c] * inv_count, m2 = sums[2 * c + 1] * inv_count;
+  const float* dp = dh + (long)bc * S;
+  const float* rp = r + (long)bc * S;
+  float* op = dr + (long)bc * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    const float rv = rp[i];
+    float dz = dp[i];
+    if (lrelu && !(rv * sc + sf > 0.f)) dz *= HPVG_LRELU_SLOPE;
+    const float xh = (rv - mu) * is;
+    op[i] = sc * (dz - m1 - xh * m2);
+  }
+}
+
+// The same with the finalize folded in (single-GPU path): every workgroup sums its channel's nsplit partial pairs itself;
+// workgroup (x = 0, b = 0) of a channel writes dbeta / dgamma (+= when accumulate).
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_fused_kernel(const float* __restrict__ dh, const float* __restrict__ r,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                        const double* __restrict__ part, int nsplit,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                        int accumulate, float* __restrict__ dr, int C, long S,
+                                                                        float inv_count, int lrelu) {
+  __shared__ float s_m1, s_m2;
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    double s1 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 0] : 0.0;
+    double s2 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 1] : 0.0;
+    s1 = hpvg_wave_sum_d(s1);
+    s2 = hpvg_wave_sum_d(s2);
+    if (k == 0) {
+      s_m1 = (float)s1 * inv_count;
+      s_m2 = (float)s2 * inv_count;
+      if (blockIdx.x == 0 && bc == c) {
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+      }
+    }
+  }
+  __syncthreads();
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  const float m1 = s_m1, m2 = s_m2;
   const float* dp = dh + (long)bc * S;
   const float* rp = r + (long)bc * S;
   float* op = dr + (long)bc * S;
@@ -670,6 +765,9 @@ inline int ew_blocks(long n) {
   if (nb > 4096) nb = 4096;
   return (int)nb;
 }
+// BatchNorm apply kernels fold the finalize in below this many elements (one round of workgroups); above, the extra
+// launch is cheaper than the per-workgroup prologue (A/B on stages 3-7: backward +0.4 %, forward neutral below the bound; fused everywhere: -1 % at stages >= 6)
+constexpr long HPVG_BN_FUSE_MAX = 1L << 23;
 inline int bn_nsplit(int B, int C, long S) {
   // enough blocks to fill the chip (>= ~1024) but at least ~2048 elements per block
   long want = (1024 + C - 1) / C;
@@ -702,6 +800,36 @@ int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* bet
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)B * (double)S,
                      eps, momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+  return hpvg_launch_status();
+}
+
+// h = lrelu?(BatchNorm_train(x)) in two launches: partial sums, then the apply kernel that finalizes its own channel
+// (statistics out, running-stat update) - hpvg_bn_train_stats_f32 + hpvg_affine_act_f32 without the finalize launch.
+int hpvg_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, float* y, int lrelu,
+                          void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!x || !y || !mean || !invstd || !scale || !shift || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  switch (hpvg_vec_width(x, S)) {
+    case 4: hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
+    case 2: hipLaunchKernelGGL(bn_stats_partial_kernel<2>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
+    default: hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
+  }
+  if ((long)B * C * S > HPVG_BN_FUSE_MAX) {
+    // large tensors: tens of thousands of apply workgroups would each repeat the finalize prologue - three launches win
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)B * (double)S,
+                       eps, momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+    int nbx = hpvg_cdiv(S, 256 * 4);
+    if (nbx > 1024) nbx = 1024;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(nbx, B * C), dim3(256), 0, s, x, (const float*)scale, (const float*)shift, y, C, S,
+                       lrelu);
+    return hpvg_launch_status();
+  }
+  const int nbx = hpvg_cdiv(S, 256 * 16);
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, x, (const double*)ws, ns, (double)B * (double)S, eps,
+                     momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, y, C, S, lrelu);
   return hpvg_launch_status();
 }
 
@@ -776,19 +904,25 @@ int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, cons
   const int ns = bn_nsplit(B, C, S);
   hipStream_t s = (hipStream_t)stream;
   double* part = (double*)ws;
-  float* sums = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
   {
     const int vw = hpvg_vec_width(dh, S) < hpvg_vec_width(r, S) ? hpvg_vec_width(dh, S) : hpvg_vec_width(r, S);
     if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
     else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
     else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
-                     sums, accumulate);
-  int nbx = hpvg_cdiv(S, 256 * 4);
-  if (nbx > 1024) nbx = 1024;
-  hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
-                     (const float*)sums, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
+  if ((long)B * C * S > HPVG_BN_FUSE_MAX) {
+    float* sums = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
+                       sums, accumulate);
+    int nbx = hpvg_cdiv(S, 256 * 4);
+    if (nbx > 1024) nbx = 1024;
+    hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
+                       (const float*)sums, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
+    return hpvg_launch_status();
+  }
+  const int nbx = hpvg_cdiv(S, 256 * 16);
+  hipLaunchKernelGGL(bn_lrelu_bwd_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
+                     (const double*)part, ns, dgamma, dbeta, accumulate, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
   return hpvg_launch_status();
 }
 

@@ -337,12 +337,10 @@ class BNAct(Function):
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
         nws = call("hpvg_bn_ws_bytes", C)
         ws = workspace(nws, dev)
-        call("hpvg_bn_train_stats_f32", ptr(r), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-             float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws),
-             ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
         h = torch.empty_like(r)
-        call("hpvg_affine_act_f32", ptr(r), ptr(stats[2]), ptr(stats[3]), ptr(h), 1 if lrelu else 0, B, C,
-             ctypes.c_long(S), stream())
+        call("hpvg_bn_train_fwd_f32", ptr(r), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(h),
+             1 if lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
         ctx.save_for_backward(r, stats, gamma, beta)
         ctx.lrelu = lrelu
         return h

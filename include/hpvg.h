@@ -63,6 +63,10 @@ size_t hpvg_bn_ws_bytes(int C);
 int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                             float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* ws,
                             size_t ws_bytes, int B, int C, long S, void* stream);
+/* the two above in two launches instead of three (the apply kernel finalizes its own channel's statistics) */
+int hpvg_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, float* y, int lrelu,
+                          void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
 /* y = LeakyReLU_opt(scale[c]*x + shift[c]) (BN apply + nn.LeakyReLU(0.2), networks_3d.py:21,54-56) */
 int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int lrelu, int B, int C, long S,
                         void* stream);
