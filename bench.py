@@ -179,16 +179,17 @@ def _parallelism(world):
     """What the ranks do (hp_vae_gan_amd/multigpu.py); the stage thresholds are the env knobs the runner reads."""
     if world == 1:
         return "single GPU"
-    pair = "rec/rand generator passes on ranks 0/1 + discriminator work split over the batch"
+    vae = "VAE stages: rank 0 alone (hipGraph replay); "
+    pair = vae + "GAN stages: rec/rand generator passes on ranks 0/1 + discriminator work split over the batch"
     if world < 4:
         return "%s (2 working ranks of %d)" % (pair, world)
     qmin = os.environ.get("HPVG_QUAD_MIN_STAGE", "5")
-    quad = "stages >= %s: generator passes x batch samples on 4 ranks with batch-split BatchNorm, discriminator work by sample and task" % qmin
+    quad = vae + "stages >= %s: generator passes x batch samples on 4 ranks with batch-split BatchNorm, discriminator work by sample and task" % qmin
     if world < 8:
         return "%s; earlier GAN stages: 2 ranks (4 working ranks of %d)" % (quad, world)
     omin = os.environ.get("HPVG_OCT_MIN_STAGE", "7")
     return ("stages >= %s: the 4 (pass, sample) jobs x 2 row slabs on 8 ranks (boundary-row swaps per conv, BatchNorm over samples and "
-            "slabs); %s; earlier GAN stages: 2 ranks (8 working ranks of %d)" % (omin, quad, world))
+            "slabs); %s; earlier GAN stages: 2 ranks (8 working ranks of %d)" % (omin, quad[len(vae):], world)).join([vae, ""])
 
 
 def main():
@@ -342,7 +343,8 @@ def main():
                                     if CONFIG == "video" else
                                     "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path); ") +
                                    "step = 1 train iteration at each pyramid stage %s" % args.stages,
-                       "stages": stages, "hipgraph_stages": [s for s in graph_stages if s in stages and s != max(stages)] if world == 1 else [],
+                       "stages": stages, "hipgraph_stages": [s for s in graph_stages if s in stages and s != max(stages)] if world == 1 else
+                       [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"],
                        "parallelism": _parallelism(world)},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
             "roofline": roof, "cpu_baseline": cpu,

@@ -505,6 +505,19 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
         real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
         opt.Z_init_size = [opt.batch_size, opt.latent_dim, *shapes[0]]
+        if netD is None and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0":
+            # VAE stages: one BatchNorm-coupled generator pass on a <= 11 K-voxel volume, a few ms of latency-bound
+            # launches - nothing to shard.  Rank 0 trains them alone as a replayed hipGraph (the single-GPU path); a
+            # training run would broadcast the stage's parameters once at its end (broadcast_module).  The other ranks
+            # wait at the next collective.  (DistStageTrainer._vae_step, every rank in lock-step with broadcast noise,
+            # stays available: HPVG_VAE_ON_RANK0=0.)
+            trainer = None
+            if rank == 0:
+                trainer = hp_train.StageTrainer(opt, netG)
+                trainer.step(real, real_zero)
+                trainer.enable_graph(real, real_zero)
+            built.append((s, trainer, real, real_zero))
+            continue
         # four working ranks from the first stage whose iteration is long enough to pay for the BatchNorm exchanges
         # (~130 small all-reduces per iteration); earlier GAN stages run on two ranks
         quad = world >= 4 and s >= int(os.environ.get("HPVG_QUAD_MIN_STAGE", "5"))
@@ -519,11 +532,19 @@ def build_bench_runner(make_opt, stages, device, rank, world):
 
         def step(self):
             for s, trainer, real, real_zero in built:
-                trainer.step(real, real_zero)
+                if trainer is not None:
+                    trainer.step(real, real_zero)
 
         def timed_stage(self, idx):
             s, trainer, real, real_zero = built[idx]
-            trainer.step(real, real_zero)
+            if trainer is not None:
+                trainer.step(real, real_zero)
             return s
 
     return Runner()
+
+
+def broadcast_module(net, src=0, group=None):
+    """Hand a module trained on one rank (VAE stages) to the others: parameters and buffers, in state_dict order."""
+    for t in list(net.parameters()) + list(net.buffers()):
+        broadcast(t.data, src=src, group=group)
