@@ -11,6 +11,8 @@ def calc_gradient_penalty(netD, real_data, fake_data, LAMBDA, device, alpha=None
     The double backward runs through ops.Conv / ConvBwdData / ConvBwdWeight / LReLUMaskMul."""
     if alpha is None:
         alpha = torch.rand(1, 1)
+    if not alpha.is_cuda:
+        alpha = ops.host_floats_to_device([float(alpha.reshape(-1)[0])], real_data.device)  # no host stall (see ops)
     alpha = alpha.reshape(1).to(device=real_data.device, dtype=torch.float32)
     interpolates = ops.lerp(real_data, fake_data, alpha)
     interpolates.requires_grad_(True)

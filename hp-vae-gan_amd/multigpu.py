@@ -242,6 +242,14 @@ class DistStageTrainer:
         broadcast(t, src=src, group=group)
         return float(t.item())
 
+    def _alpha_to_device(self, alpha):
+        if alpha.is_cuda:
+            return alpha.reshape(1).to(self.dev, torch.float32).clone()
+        if self.dev.type == "cuda":
+            from . import ops
+            return ops.host_floats_to_device([float(alpha.reshape(-1)[0])], self.dev)   # no host stall
+        return alpha.reshape(1).to(self.dev, torch.float32).clone()
+
     def _bcast_noise(self, ref):
         n = self.be.noise(ref) if self.rank == 0 else torch.empty_like(ref)
         broadcast(n, src=0)
@@ -300,7 +308,7 @@ class DistStageTrainer:
         # -- D step on this rank's batch sample (same alpha on both ranks, drawn on rank 0's CPU generator)
         if alpha is None:
             alpha = torch.rand(1, 1) if r == 0 else torch.zeros(1, 1)
-        a = alpha.reshape(1).to(self.dev, torch.float32).clone()
+        a = self._alpha_to_device(alpha)
         broadcast(a, src=0, group=g)
         o.zero_D()
         errD_real = be.wgan_mean(netD(real_b), -1.0) * 0.5
@@ -383,7 +391,7 @@ class DistStageTrainer:
             real_b = real[b:b + 1].narrow(real.dim() - 2, r0, r1 - r0).contiguous()
             if alpha is None:
                 alpha = torch.rand(1, 1) if self.rank == 0 else torch.zeros(1, 1)
-            a = alpha.reshape(1).to(self.dev, torch.float32).clone()
+            a = self._alpha_to_device(alpha)
             broadcast(a, src=0, group=g_all)
             o.zero_D()
             zero = torch.zeros((), device=self.dev)

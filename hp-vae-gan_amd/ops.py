@@ -681,6 +681,25 @@ class GradPenalty(Function):
         return dg, None
 
 
+_pinned_ring = []
+
+
+def host_floats_to_device(values, device):
+    """A few host floats -> a device tensor WITHOUT stalling the host: a plain `.to(device)` from pageable memory is a
+    synchronous copy on the compute stream, i.e. the host waits for every kernel queued so far (the whole iteration up to
+    the gradient penalty's alpha) and then has to re-fill the queue.  Staged through a small ring of pinned buffers."""
+    vals = [float(v) for v in values]
+    if device.type != "cuda":
+        return torch.tensor(vals, dtype=torch.float32, device=device)
+    if not _pinned_ring:
+        _pinned_ring.extend([0, [torch.empty(16, dtype=torch.float32).pin_memory() for _ in range(16)]])
+    slot = _pinned_ring[1][_pinned_ring[0] % 16]
+    _pinned_ring[0] += 1
+    for i, v in enumerate(vals):
+        slot[i] = v
+    return slot[:len(vals)].to(device, non_blocking=True)
+
+
 def lerp(a, b, alpha):
     """alpha*a + (1-alpha)*b with a device scalar alpha (no autograd: the result becomes a leaf, modules/utils.py:9-10)."""
     a, b = _c(a.detach()), _c(b.detach())
