@@ -413,3 +413,92 @@ def test_packed_weight_cache_follows_the_weight(ops):
     del w, wp0
     w2 = _rand(64, 64, 3, 3, 3, seed=3, scale=0.05).to(DEV)         # may or may not land on the old address
     assert_close(ops.conv_fwd_raw(x, w2, None), O.conv(x.cpu(), w2.cpu()), RTOL, "cache.new-tensor(%s)" % (w2.data_ptr() == addr))
+
+
+def test_full_size_conv_family_properties(ops):
+    """BASELINE configs[2] finest level (B=2, 64->64, 13 x 144 x 256: 958 464 voxels), where the oracle takes minutes: the
+    three conv kernels are tied together by size-independent properties instead -
+      * locality: any crop of the output equals the oracle's conv of the matching input crop (+1 voxel of context);
+      * adjointness: <conv(x, w), dy> = <x, bwd_data(dy, w)> = <w, bwd_weight(dy, x)>  (one number, three kernels);
+      * linearity of the forward kernel in its input."""
+    B, C, T, H, W = 2, 64, 13, 144, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+    dy = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+    w = _rand(C, C, 3, 3, 3, seed=21, scale=0.03).to(DEV)
+    b = _rand(C, seed=22).to(DEV)
+    y = ops.conv_fwd_raw(x, w, b)
+    # locality: three crops (a corner with zero padding on three sides, an interior block, the far corner)
+    for (t0, t1, h0, h1, w0, w1) in [(0, 3, 0, 6, 0, 9), (5, 8, 70, 77, 120, 131), (10, 13, 138, 144, 247, 256)]:
+        ts, hs, ws_ = max(t0 - 1, 0), max(h0 - 1, 0), max(w0 - 1, 0)
+        te, he, we = min(t1 + 1, T), min(h1 + 1, H), min(w1 + 1, W)
+        want = O.conv(x[1:2, :, ts:te, hs:he, ws_:we].cpu(), w.cpu(), b.cpu())
+        want = want[:, :, t0 - ts:t0 - ts + (t1 - t0), h0 - hs:h0 - hs + (h1 - h0), w0 - ws_:w0 - ws_ + (w1 - w0)]
+        # a crop edge that is not an image edge saw real neighbours in the full conv, zero padding in the cropped one:
+        # the +1 context above makes every compared voxel see identical inputs
+        assert_close(y[1:2, :, t0:t1, h0:h1, w0:w1], want, RTOL, "fullsize.crop(%d,%d,%d)" % (t0, h0, w0))
+    # adjointness (bias-free)
+    y0 = ops.conv_fwd_raw(x, w, None)
+    dx = ops.conv_fwd_raw(dy, w, None, flip=True)
+    dw = ops.conv_bwd_weight_raw(dy, x, w.shape)
+    a1 = float((y0.double() * dy.double()).sum())
+    a2 = float((x.double() * dx.double()).sum())
+    a3 = float((w.double() * dw.double()).sum())
+    scale = float(y0.double().norm() * dy.double().norm())
+    assert abs(a1 - a2) <= 1e-5 * scale and abs(a1 - a3) <= 1e-5 * scale, (a1, a2, a3, scale)
+    # linearity
+    x2 = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+    lhs = ops.conv_fwd_raw(1.5 * x + x2, w, None)
+    rhs = 1.5 * y0 + ops.conv_fwd_raw(x2, w, None)
+    assert_close(lhs, rhs, 1e-4, "fullsize.linearity")
+
+
+def test_full_size_batchnorm_properties(ops):
+    """Finest-level BatchNorm + LeakyReLU (B=2, 64 ch, 13 x 144 x 256): before the activation the output has per-channel
+    mean beta and variance gamma^2 (eps-corrected), whatever the input; dbeta / dgamma equal the direct sums."""
+    B, C, T, H, W = 2, 64, 13, 144, 256
+    g = torch.Generator(device=DEV).manual_seed(6)
+    r = (torch.randn(B, C, T, H, W, device=DEV, generator=g) * 3.0 + 0.7).requires_grad_(True)
+    gamma = (torch.rand(C, device=DEV, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, device=DEV, generator=g).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    z = ops.BNAct.apply(r, gamma, beta, rm, rv, 0.1, 1e-5, False)
+    zm = z.double().mean(dim=(0, 2, 3, 4))
+    zv = z.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert_close(zm.float(), beta.detach(), 1e-4, "fullsize.bn.mean", atol=1e-5)
+    var_in = r.detach().double().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert_close(zv.float(), (gamma.detach().double() ** 2 * var_in / (var_in + 1e-5)).float(), 1e-4, "fullsize.bn.var")
+    dh = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+    z.backward(dh)
+    assert_close(beta.grad, dh.double().sum(dim=(0, 2, 3, 4)).float(), 1e-4, "fullsize.bn.dbeta", atol=1e-2)
+    xhat = (r.detach().double() - r.detach().double().mean(dim=(0, 2, 3, 4), keepdim=True)) / torch.sqrt(var_in + 1e-5).view(1, -1, 1, 1, 1)
+    assert_close(gamma.grad, (dh.double() * xhat).sum(dim=(0, 2, 3, 4)).float(), 1e-4, "fullsize.bn.dgamma", atol=1e-2)
+    # dr sums to zero per channel and is orthogonal to xhat (the two projections BatchNorm's backward removes)
+    dr = r.grad.double()
+    n = B * T * H * W
+    assert float(dr.sum(dim=(0, 2, 3, 4)).abs().max()) <= 1e-6 * n
+    assert float((dr * xhat).sum(dim=(0, 2, 3, 4)).abs().max()) <= 1e-6 * n
+
+
+@pytest.mark.parametrize("Cin,Cout", [(64, 3), (3, 64), (64, 1), (128, 64)])
+def test_full_size_head_and_tail_convs_by_crops(ops, Cin, Cout):
+    """The other layer shapes of the path at the finest level's size (tails 64->3 / 64->1 on the narrow-output kernel,
+    head 3->64, decoder head 128->64 at its own largest size): output crops against the oracle, forward and backward-data."""
+    B, T, H, W = (2, 13, 144, 256) if Cin != 128 else (2, 4, 18, 33)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(B, Cin, T, H, W, device=DEV, generator=g)
+    dy = torch.randn(B, Cout, T, H, W, device=DEV, generator=g)
+    w = _rand(Cout, Cin, 3, 3, 3, seed=23, scale=0.05).to(DEV)
+    b = _rand(Cout, seed=24).to(DEV)
+    y = ops.conv_fwd_raw(x, w, b)
+    dx = ops.conv_fwd_raw(dy, w, None, flip=True)
+    wf = w.cpu().flip(2, 3, 4).transpose(0, 1).contiguous()     # backward-data = conv with the flipped, transposed weight
+    crops = [(0, 3, 0, 6, 0, 9), (T - 3, T, H - 6, H, W - 9, W)] + ([(5, 8, 70, 77, 120, 131)] if T > 8 else [])
+    for (t0, t1, h0, h1, w0, w1) in crops:
+        ts, hs, ws_ = max(t0 - 1, 0), max(h0 - 1, 0), max(w0 - 1, 0)
+        te, he, we = min(t1 + 1, T), min(h1 + 1, H), min(w1 + 1, W)
+        sl = (slice(0, 1), slice(None), slice(ts, te), slice(hs, he), slice(ws_, we))
+        inner = (slice(None), slice(None), slice(t0 - ts, t0 - ts + t1 - t0), slice(h0 - hs, h0 - hs + h1 - h0),
+                 slice(w0 - ws_, w0 - ws_ + w1 - w0))
+        assert_close(y[0:1, :, t0:t1, h0:h1, w0:w1], O.conv(x[sl].cpu(), w.cpu(), b.cpu())[inner], RTOL, "crop.fwd")
+        assert_close(dx[0:1, :, t0:t1, h0:h1, w0:w1], O.conv(dy[sl].cpu(), wf)[inner], RTOL, "crop.bwd_data")
