@@ -30,6 +30,7 @@ struct WgradArgs {
   float* part;
   int B, Cin, Cout, T, H, W;
   int Th, Tw, RS, DS, XS, QK, nth, ntw, S, ncb, nob;
+  int S0;  // KT == 3: persistent slots of the outer time taps (dt = 0, 2); the centre tap has S (>= S0)
   int in_lrelu;
 };
 
@@ -49,11 +50,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   // XCD.  The KT workgroups of a slot walk the SAME tile list (time-major, below), so at any moment they hold the same
   // dY tile and the X planes t-1, t, t+1, which the neighbouring slots (tiles t-1, t+1 of the same spatial position)
   // need as well: each plane is fetched from HBM once and hits in the XCD's L2 for its other readers.
+  // The outer taps (dt = 0, 2) have no input plane for 1 of the T output planes, i.e. (T-1)/T of the centre tap's work:
+  // they get S0 < S slots, so that every workgroup of the launch ends at the same time (with equal slot counts the
+  // outer-tap workgroups idled 1/T of the launch: 8 % at T = 13, 25 % at T = 4).  Ids: slots < S0 carry all three taps
+  // (tap fastest), the centre tap's extra slots follow.
   const int nz = a.nob * a.ncb;
   const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
-  const int dt = L % KT;
-  const int slot = (L / KT) % a.S;
-  const int z = L / (KT * a.S);
+  const int Stot = KT == 3 ? 2 * a.S0 + a.S : a.S;
+  const int idx = L % Stot;
+  const int z = L / Stot;
+  int dt = 0, slot = idx, nslot = a.S;
+  if (KT == 3) {
+    if (idx < 3 * a.S0) {
+      dt = idx % 3;
+      slot = idx / 3;
+      nslot = dt == 1 ? a.S : a.S0;
+    } else {
+      dt = 1;
+      slot = a.S0 + idx - 3 * a.S0;
+    }
+  }
   const int ob = z / a.ncb, cb = z % a.ncb;
   const int RS = a.RS, DS = a.DS, XS = a.XS;
   const int BUF = 64 * (DS + XS);
@@ -162,8 +178,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int nsteps = a.QK >> 2;  // K-loop iterations (4 positions = 2 MFMA k-steps each)
   int cur = 0;
-  for (; tile < ntiles; tile += a.S) {
-    const int next = tile + a.S;
+  for (; tile < ntiles; tile += nslot) {
+    const int next = tile + nslot;
     const bool have_next = next < ntiles;
     float* bufc = lds + cur * BUF;
     int cnext = 64;                // next channel to stage (64 = nothing left)
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_narrow_reduce_kernel(const flo
 }
 
 // dW[o][c][dt][tap9] = sum_s part[s][dt][z][tap9][o%64][c%64]; one thread per slab element, fixed order.
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int KT, int nob,
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S1, int S0, int KT, int nob,
                                          int ncb, int Cout, int Cin, int accumulate) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per_s = (long)KT * nob * ncb * 9 * 4096;
@@ -449,6 +465,7 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* 
   const int dt = (int)r;
   const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 64 + c64;
   if (o >= Cout || c >= Cin) return;
+  const int S = (KT == 3 && dt != 1) ? S0 : S1;  // slots that wrote a slab for this time tap
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int s = 0;
   for (; s + 4 <= S; s += 4) {
@@ -506,6 +523,7 @@ __global__ void channel_sum_finish_kernel(const double* __restrict__ part, int n
 struct WPlan {
   int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb;
   size_t lds;
+  int S0;  // slots of the outer time taps (KT == 3), <= S
 };
 
 WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
@@ -541,6 +559,19 @@ WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
     long cap = (long)HPVG_NUM_CU / ((long)KT * nob * ncb);  // one persistent workgroup per CU
     if (cap < 1) cap = 1;
     best.S = (int)(ntiles < cap ? ntiles : cap);
+    best.S0 = best.S;
+    if (KT == 3 && T >= 2 && best.S >= 2) {
+      // split the 3*S workgroups of a channel-block pair so that tiles-with-work per workgroup are equal:
+      // centre tap: ntiles / S1, outer taps: ntiles * (T-1)/T / S0
+      const long Stot = 3L * best.S;
+      long S1 = (Stot * T + (3L * T - 2) / 2) / (3L * T - 2);
+      if (S1 > ntiles) S1 = ntiles;
+      long S0 = (Stot - S1) / 2;
+      if (S0 < 1) S0 = 1;
+      if (S0 > S1) S0 = S1;
+      best.S = (int)S1;
+      best.S0 = (int)S0;
+    }
   }
   return best;
 }
@@ -657,9 +688,9 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   a.part = (float*)((char*)ws + 256);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
-  a.S = p.S; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
+  a.S = p.S; a.S0 = p.S0; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(p.S * KT * p.nob * p.ncb);
+  const dim3 grid((KT == 3 ? 2 * p.S0 + p.S : p.S) * p.nob * p.ncb);
   const int njd = p.DS > 256 ? 2 : 1, njx = p.XS > 256 ? 2 : 1;
 #define HPVG_WG_LAUNCH(K, D, X)                                                                                        \
   {                                                                                                                    \
@@ -685,7 +716,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   int st = hpvg_launch_status();
   if (st != HPVG_OK) return st;
   const long per_s = (long)KT * p.nob * p.ncb * 9 * 4096;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(hpvg_cdiv(per_s, 256)), dim3(256), 0, s, (const float*)a.part, dw, p.S, KT,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(hpvg_cdiv(per_s, 256)), dim3(256), 0, s, (const float*)a.part, dw, p.S, p.S0, KT,
                      p.nob, p.ncb, Cout, Cin, accumulate);
   return hpvg_launch_status();
 }
