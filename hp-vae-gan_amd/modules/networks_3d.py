@@ -4,7 +4,7 @@ from . import _nets
 from .. import ops
 
 __all__ = ['ConvBlock3D', 'ConvBlock3DSN', 'FeatureExtractor', 'Encode3DVAE', 'WDiscriminator3D', 'GeneratorHPVAEGAN',
-           'GeneratorSG', 'GeneratorCSG', 'weights_init', 'reparameterize']
+           'GeneratorSG', 'GeneratorCSG', 'WDiscriminatorBaselines', 'weights_init', 'reparameterize']
 
 weights_init = _nets.weights_init
 
@@ -54,3 +54,7 @@ class GeneratorSG(_nets.GeneratorSG):
 
 class GeneratorCSG(_nets.GeneratorCSG):
     """SinGAN-3D baseline with shared head / tail, the default of train_video_baselines.py (reference: networks_3d.py:213-269)."""
+
+
+class WDiscriminatorBaselines(_nets.WDiscriminatorBaselines):
+    """The baselines' BatchNorm critic on a zero-padded volume (reference: networks_3d.py:184-210)."""

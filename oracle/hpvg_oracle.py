@@ -277,13 +277,13 @@ def baseline_train_step(PG, PD, opt, scale_idx, real, Z_init, noise_init, noises
     gparams = {k: v for k, v in PG.items() if is_param(k) and any(k.startswith(t) for t in trained)}
     dparams = {k: v for k, v in PD.items() if is_param(k)}
     for j in range(opt.Dsteps):
-        errD_real = -discriminator_forward(real, PD, opt).mean()
+        errD_real = -any_discriminator_forward(real, PD, opt).mean()
         if j == opt.Dsteps - 1:
             fake = gen_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
         else:
             with torch.no_grad():
                 fake = gen_forward(PG, opt, noise_init, noise_amps, 'rand', noises)
-        errD_fake = discriminator_forward(fake.detach(), PD, opt).mean()
+        errD_fake = any_discriminator_forward(fake.detach(), PD, opt).mean()
         gp = gradient_penalty(PD, opt, real, fake, opt.lambda_grad, alphas[j])
         dgrads = torch.autograd.grad(errD_real + errD_fake + gp, list(dparams.values()), allow_unused=True)
         out['gradsD'] = {k: (g.clone() if g is not None else None) for k, g in zip(dparams.keys(), dgrads)}
@@ -291,7 +291,7 @@ def baseline_train_step(PG, PD, opt, scale_idx, real, Z_init, noise_init, noises
             if g is not None:
                 with torch.no_grad():
                     adam_step(p, g, adam_d.setdefault(k, {}), opt.lr_d, opt.beta1)
-    errG = -discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
+    errG = -any_discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
     total = errG
     if opt.alpha > 0:
         generated = gen_forward(PG, opt, Z_init, noise_amps, 'rec', None)
@@ -377,10 +377,30 @@ def discriminator_forward(x, P, opt, training=True):
     return conv(h, P['tail.weight'], P['tail.bias'])
 
 
+def discriminator_baselines_forward(x, P, opt, training=True):
+    """WDiscriminatorBaselines.forward (networks_3d.py:184-210): input zero-padded by num_layer + 2 voxels per side, head
+    = conv (padding padd_size) + LeakyReLU (NO norm), num_layer x [conv + BatchNorm(batch stats) + LeakyReLU], tail conv.
+    Keys: head.conv.*, body.blockI.{conv,norm}.*, tail.*"""
+    p = opt.num_layer + 2
+    same = opt.padd_size == 1
+    cv = conv if same else conv_valid
+    h = leaky_relu(cv(F.pad(x, (p,) * 6), P['head.conv.weight'], P['head.conv.bias']))
+    for i in range(opt.num_layer):
+        h = (_bn_block if same else _bn_block_valid)(h, P, 'body.block%d' % i)
+    return cv(h, P['tail.weight'], P['tail.bias'])
+
+
+def any_discriminator_forward(x, P, opt, training=True):
+    """WDiscriminator3D/2D (spectral norm) or WDiscriminatorBaselines (BatchNorm), told apart by the state-dict keys."""
+    if 'head.conv.weight_orig' in P:
+        return discriminator_forward(x, P, opt, training)
+    return discriminator_baselines_forward(x, P, opt, training)
+
+
 def gradient_penalty(PD, opt, real, fake, lam, alpha):
     """modules/utils.py:4-19 with the scalar alpha injected."""
     xhat = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
-    out = discriminator_forward(xhat, PD, opt)
+    out = any_discriminator_forward(xhat, PD, opt)
     g = torch.autograd.grad(out, xhat, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True)[0]
     return ((g.norm(2, dim=1) - 1) ** 2).mean() * lam
 

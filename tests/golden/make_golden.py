@@ -256,7 +256,7 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
     return fx
 
 
-def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, generator='GeneratorSG'):
+def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, generator='GeneratorSG', discriminator='WDiscriminator3D'):
     """train_video_baselines.py:93-173 driven around the reference's GeneratorSG / GeneratorCSG + WDiscriminator3D."""
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
@@ -266,7 +266,7 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
     for _ in range(scale_idx):
         netG.init_next_stage()
     perturb(netG, gen)
-    D = n3.WDiscriminator3D(opt)
+    D = getattr(n3, discriminator)(opt)
     perturb(D, gen)
     optimizerD = optim.Adam(D.parameters(), lr=opt.lr_d, betas=(opt.beta1, 0.999))
     for block in netG.body[:-opt.train_depth]:
@@ -293,6 +293,7 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
     fx = {'opt': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, bool, list, str))}, 'scale_idx': scale_idx,
           'real': real, 'Z_init': Z_init, 'G_init': sd_clone(netG), 'D_init': sd_clone(D), 'noise_amps_init': list(noise_amps),
           'iters': []}
+    km = KinkMargin(netG, D)
     for it in range(n_iters):
         with Recorder() as rec:
             noise_init = images.generate_noise(ref=Z_init)
@@ -330,6 +331,9 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
                             'gradient_penalty': gp.detach().clone(), 'errG': errG.detach().clone(), 'rec_loss': rec_loss.detach().clone(),
                             'fake': fake.detach().clone(), 'generated': generated.detach().clone(), 'gradsD': gradsD, 'gradsG': gradsG,
                             'noise_amps': list(noise_amps), 'G_after': sd_clone(netG), 'D_after': sd_clone(D)})
+    km.close()
+    fx['kink_margin'] = km.margin
+    fx['seed'] = seed
     return fx
 
 
@@ -484,6 +488,10 @@ def main():
         # the baselines script's DEFAULT generator (64-channel features between stages, head/tail trained along)
         'baseline3d_csg_s2.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=3), 2, 1, seed=109,
                                                            generator='GeneratorCSG'),
+        # the baselines' own critic: zero-padded input, BatchNorm inside (its gradient penalty differentiates BatchNorm twice)
+        'baseline3d_dbl_s1.pt': lambda: with_kink_margin(lambda sd: run_baseline_steps(
+            images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=1), 1, 1, seed=sd,
+            discriminator='WDiscriminatorBaselines'), 110, 6e-6),
         'sample3d_s3.pt': lambda: run_sampling(images, n3, make_opt(vae_levels=2), 3, 3, seed=106),
         # non-default training depth: the last two blocks train (no detach between them, scaled learning rates), and
         # --train-all with every level open (train_video.py:74-86, networks_3d.py:391-392)

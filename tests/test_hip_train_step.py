@@ -84,8 +84,10 @@ def test_smoke_entry():
     run_smoke()
 
 
-@pytest.mark.parametrize("fname,generator", [("baseline3d_s2.pt", "GeneratorSG"), ("baseline3d_csg_s2.pt", "GeneratorCSG")])
-def test_baseline_singan_step_matches_reference(fname, generator):
+@pytest.mark.parametrize("fname,generator,critic", [("baseline3d_s2.pt", "GeneratorSG", "WDiscriminator3D"),
+                                                    ("baseline3d_csg_s2.pt", "GeneratorCSG", "WDiscriminator3D"),
+                                                    ("baseline3d_dbl_s1.pt", "GeneratorSG", "WDiscriminatorBaselines")])
+def test_baseline_singan_step_matches_reference(fname, generator, critic):
     """BASELINE config 5 (GeneratorSG) and the baselines script's default GeneratorCSG: BaselineStageTrainer (HIP)
     against the reference-generated fixtures."""
     from helpers import NoiseFeed, hip_opt
@@ -101,7 +103,8 @@ def test_baseline_singan_step_matches_reference(fname, generator):
     assert list(netG.state_dict().keys()) == list(fx["G_init"].keys())
     netG.load_state_dict(fx["G_init"])
     netG.to(dev)
-    netD = networks_3d.WDiscriminator3D(opt)
+    netD = getattr(networks_3d, critic)(opt)
+    assert list(netD.state_dict().keys()) == list(fx["D_init"].keys())
     netD.load_state_dict(fx["D_init"])
     netD.to(dev)
     opt.Noise_Amps = list(fx["noise_amps_init"])

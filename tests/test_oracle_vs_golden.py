@@ -222,7 +222,7 @@ def test_c_restatement_of_conv_matches():
         assert_close(y, want, 1e-5, "conv_direct.c")
 
 
-@pytest.mark.parametrize("fname", ["baseline3d_s2.pt", "baseline3d_csg_s2.pt"])
+@pytest.mark.parametrize("fname", ["baseline3d_s2.pt", "baseline3d_csg_s2.pt", "baseline3d_dbl_s1.pt"])
 def test_baseline_singan_step(fname):
     """SinGAN-3D baselines (BASELINE config 5: GeneratorSG; and train_video_baselines.py's default GeneratorCSG with its
     head / tail optimizer groups): oracle step vs the reference-generated fixture."""
