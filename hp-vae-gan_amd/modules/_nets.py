@@ -275,7 +275,9 @@ class GeneratorHPVAEGAN(nn.Module):
             return ops.Reparam.apply(mu, logvar, self._noise_like(mu))
         return self._noise_like(mu)
 
-    def forward(self, video, noise_amp, noise_init=None, sample_init=None, mode='rand'):
+    def forward(self, video, noise_amp, noise_init=None, sample_init=None, mode='rand', stop_idx=None):
+        """stop_idx (not in the reference; default None = all levels): run the refinement only up to body[stop_idx - 1] -
+        the level-pipeline schedule (pipeline.py) keeps the remaining levels on other GPUs."""
         if sample_init is not None:
             assert len(self.body) > sample_init[0], "Strating index must be lower than # of body blocks"
 
@@ -288,9 +290,9 @@ class GeneratorHPVAEGAN(nn.Module):
         vae_out = ops.TanhRes.apply(self.decoder(z_vae), None)
 
         if sample_init is not None:
-            x_prev_out = self.refinement_layers(sample_init[0], sample_init[1], noise_amp, mode)
+            x_prev_out = self.refinement_layers(sample_init[0], sample_init[1], noise_amp, mode, stop_idx)
         else:
-            x_prev_out = self.refinement_layers(0, vae_out, noise_amp, mode)
+            x_prev_out = self.refinement_layers(0, vae_out, noise_amp, mode, stop_idx)
 
         if noise_init is None:
             return x_prev_out, vae_out, (mu, logvar)
@@ -301,8 +303,8 @@ class GeneratorHPVAEGAN(nn.Module):
             return hp_utils.images.level_shape_3d(index, self.opt)
         return hp_utils.images.level_shape_2d(index, self.opt)
 
-    def refinement_layers(self, start_idx, x_prev_out, noise_amp, mode):
-        for idx, block in enumerate(self.body[start_idx:], start_idx):
+    def refinement_layers(self, start_idx, x_prev_out, noise_amp, mode, stop_idx=None):
+        for idx, block in enumerate(self.body[start_idx:stop_idx], start_idx):
             if self.opt.vae_levels == idx + 1 and not self.opt.train_all:
                 x_prev_out.detach_()
             size = self._level_size(idx + 1)

@@ -335,10 +335,11 @@ def num_body(P):
 
 
 def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='rand', noises=None, training=True,
-                      sample_init=None, level_fn=None):
+                      sample_init=None, level_fn=None, stop=None):
     """GeneratorHPVAEGAN.forward (networks_3d.py:367-406).  `noises` is an iterator yielding the N(0,1) draws in
     reference order (reparameterisation eps first, then one tensor per noisy level), or a callable(shape) -> tensor.
     sample_init = (start_index, tensor): the refinement restarts from that level's tensor (generation path).
+    stop: run refinement levels [start, stop) only (the level-pipeline tests keep the rest on other ranks).
     level_fn(idx, inp, up, f) -> x, optional: wraps the evaluation f(inp, up) of refinement level idx+1 (the multi-GPU
     tests cut the level into row slabs there); None = f(inp, up)."""
     def draw(shape):
@@ -354,7 +355,7 @@ def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='ran
         z = noise_init
     vae_out = torch.tanh(_stack7(z, P, 'decoder', opt.num_layer))
     start, x = (0, vae_out) if sample_init is None else (sample_init[0], sample_init[1])
-    for idx in range(start, num_body(P)):
+    for idx in range(start, num_body(P) if stop is None else stop):
         if opt.vae_levels == idx + 1 and not opt.train_all:
             x = x.detach()
             if idx == 0:

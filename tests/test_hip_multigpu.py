@@ -221,3 +221,69 @@ def test_two_rank_row_slabs_match_whole_image(fname):
             assert set(whole) == set(part)
             for k in whole:
                 assert_close(part[k], whole[k], 1e-3, "%s.rank%d.%s.%s" % (fname, r, which, k), atol=bn_bias_atol(k, whole))
+
+
+def _pipe_worker(rank, world, port, fname, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import NoiseFeed, hip_opt, load_golden
+    from hp_vae_gan_amd import pipeline, train as hp_train
+    from hp_vae_gan_amd.modules import networks_2d, networks_3d
+    fx = load_golden(fname)
+    dims, s = fx["dims"], fx["scale_idx"]
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], dims, s, dev)
+    nets = networks_3d if dims == 3 else networks_2d
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(s):
+        netG.init_next_stage()
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    netD = getattr(nets, opt.discriminator)(opt)
+    netD.load_state_dict(fx["D_init"])
+    netD.to(dev)
+    opt.Noise_Amps = list(fx["noise_amps_init"])
+    rec = fx["iters"][0]
+    opt.Z_init_size = list(rec["noise_init"].shape)
+    tr = pipeline.LevelPipelineTrainer(opt, netG, netD, pipeline.HipPipeBackend(opt), hp_train.generator_param_groups(opt, netG), dims=dims)
+    noises = list(rec["noises"])
+    feed = list(noises[:2]) if tr.first else []
+    noisy = [k for k in range(1, s + 1) if dims == 2 or k >= opt.vae_levels]
+    feed += [t for k, t in zip(noisy, noises[2:]) if tr.a <= k <= tr.b]
+    netG.noise_source = NoiseFeed(feed, dev)
+    out = tr.step(fx["real"].to(dev), fx["real_zero"].to(dev), noise_init=rec["noise_init"].to(dev), alpha=rec["alpha"])
+    tr.broadcast_levels()
+    torch.cuda.synchronize()
+    torch.save({"out": out, "amps": opt.Noise_Amps, "parts": tr.parts,
+                "G": {k: v.detach().cpu() for k, v in netG.state_dict().items()},
+                "D": {k: v.detach().cpu() for k, v in netD.state_dict().items()}}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step3d_gan_s3_td2.pt", 3), ("step2d_gan_s2.pt", 2)])
+def test_level_pipeline_hip_matches_reference(fname, world):
+    """pipeline.LevelPipelineTrainer with the real kernels: levels spread over 2 / 3 processes (sharing the box's GPU),
+    level outputs forward, their gradients back, global clip norm - the reference's post-step parameters on every rank."""
+    from helpers import assert_close, load_golden
+    from oracle import hpvg_oracle as O
+    fx = load_golden(fname)
+    rec = fx["iters"][0]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_pipe_worker, args=(world, _free_port(), fname, d), nprocs=world, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    lr = fx["opt"]["lr_g"]
+    assert len(got[0]["parts"]) == world
+    for r in range(world):
+        assert got[r]["amps"] == pytest.approx(rec["noise_amps"], rel=1e-4)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "rec_loss"):
+            assert_close(torch.tensor(got[r]["out"][k]), rec[k].float().reshape(()), 1e-3, "%s.rank%d.%s" % (fname, r, k))
+        assert_close(torch.tensor(got[r]["out"]["errG"]), rec["errG"].float().reshape(()), 3e-3, "%s.rank%d.errG" % (fname, r))
+        for k, v in rec["G_after"].items():
+            if O.is_param(k):
+                assert_close(got[r]["G"][k], v, 1e-3, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
+        for k, v in rec["D_after"].items():
+            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
+                assert_close(got[r]["D"][k], v, 1e-3, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)

@@ -50,7 +50,7 @@ class OracleNet(nn.Module):
     def P(self):
         return {k: getattr(self, k.replace(".", "__")) for k in self.keys}
 
-    def forward(self, x, noise_amp=None, noise_init=None, sample_init=None, mode="rand"):
+    def forward(self, x, noise_amp=None, noise_init=None, sample_init=None, mode="rand", stop_idx=None):
         O = self.O
         if self.kind == "D":
             if self.halo is None:
@@ -76,7 +76,8 @@ class OracleNet(nn.Module):
                     be.set_sync_bn(None, whole_batch_sync)
                 return plan.gather(y, H) if idx + 1 < nbody else y
         return O.generator_forward(self.P(), self.opt, self.dims, x, noise_amp, noise_init=noise_init, mode=mode,
-                                   noises=lambda shape: src(torch.empty(shape)), level_fn=level_fn)
+                                   noises=lambda shape: src(torch.empty(shape)), level_fn=level_fn, sample_init=sample_init,
+                                   stop=stop_idx)
 
 
 class _halo_convs:
