@@ -179,6 +179,8 @@ def _parallelism(world):
     """What the ranks do (hp_vae_gan_amd/multigpu.py); the stage thresholds are the env knobs the runner reads."""
     if world == 1:
         return "single GPU"
+    if os.environ.get("HPVG_PARALLELISM", "") == "levels":
+        return "level pipeline: contiguous pyramid levels per rank (finest level + D on the last), level outputs sent forward, gradients back (%d ranks)" % world
     vae = "VAE stages: rank 0 alone (hipGraph replay); "
     pair = vae + "GAN stages: rec/rand generator passes on ranks 0/1 + discriminator work split over the batch"
     if world < 4:
@@ -344,7 +346,8 @@ def main():
                                     "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path); ") +
                                    "step = 1 train iteration at each pyramid stage %s" % args.stages,
                        "stages": stages, "hipgraph_stages": [s for s in graph_stages if s in stages and s != max(stages)] if world == 1 else
-                       [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"],
+                       [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"
+                        and os.environ.get("HPVG_PARALLELISM", "") != "levels"],
                        "parallelism": _parallelism(world)},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
             "roofline": roof, "cpu_baseline": cpu,

@@ -513,6 +513,14 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
         real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
         opt.Z_init_size = [opt.batch_size, opt.latent_dim, *shapes[0]]
+        if os.environ.get("HPVG_PARALLELISM", "") == "levels":
+            # the north_star's partition (pipeline.py): contiguous levels per rank; bounded by the rank holding the finest
+            # level + D (<= ~1.2x), which is why it is not the default schedule
+            from . import pipeline
+            trainer = pipeline.LevelPipelineTrainer(opt, netG, netD, pipeline.HipPipeBackend(opt),
+                                                    hp_train.generator_param_groups(opt, netG), dims=3)
+            built.append((s, trainer, real, real_zero))
+            continue
         if netD is None and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0":
             # VAE stages: one BatchNorm-coupled generator pass on a <= 11 K-voxel volume, a few ms of latency-bound
             # launches - nothing to shard.  Rank 0 trains them alone as a replayed hipGraph (the single-GPU path); a
