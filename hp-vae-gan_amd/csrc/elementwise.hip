@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restric
   const float v = g[0] * coef;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v;
 }
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = 0.f;
+}
 // out = a + b
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                    float* __restrict__ out, long n) {
@@ -1041,7 +1044,11 @@ int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti,
                                     void* stream) {
   if (!dy || !dx || BC < 1) return HPVG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dx, 0, (size_t)BC * Ti * Hi * Wi * sizeof(float), s) != hipSuccess) return HPVG_ERR_LAUNCH;
+  // a kernel, not hipMemsetAsync: inside a captured hipGraph the memset NODE is not reliably ordered against the kernel
+  // nodes around it on this runtime (ROCm 7.2) - replays after a device synchronise scattered into a buffer that was
+  // zeroed too late or not at all (found with tools/soak.py: the clip norm went to inf in graph mode only)
+  const long nin = BC * Ti * Hi * Wi;
+  hipLaunchKernelGGL(zero_kernel, dim3(ew_blocks(nin)), dim3(256), 0, s, dx, nin);
   const long n = BC * To * Ho * Wo;
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, BC, Ti, Hi, Wi, To, Ho, Wo,
                      ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));

@@ -60,10 +60,12 @@ def adjust_scales2image(size, opt):
 def generate_noise(ref=None, size=None, type='normal', emb_size=None, device=None):
     """Noise tensor shaped like `ref` or `size` (reference: utils/images.py:39-57).  Random bits come from torch's
     generator of the target device (the CPU generator when opt-in parity mode hands CPU noise in)."""
+    # (the reference fills zeros first; every element is overwritten by the draw below, and torch.zeros is a
+    # hipMemsetAsync, whose node inside a captured hipGraph is not reliably ordered on this runtime - see elementwise.hip)
     if ref is not None:
-        noise = torch.zeros_like(ref)
+        noise = torch.empty_like(ref)
     elif size is not None:
-        noise = torch.zeros(*size, device=device)  # allocated on the target device (no host tensor, no H2D copy)
+        noise = torch.empty(*size, device=device)  # allocated on the target device (no host tensor, no H2D copy)
     else:
         raise Exception("ref or size must be applied")
 
