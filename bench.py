@@ -258,6 +258,12 @@ def main():
                 trainer.step(real, real_zero)
                 return s
 
+            def check_finite(self):
+                for s, trainer, _, _ in built:
+                    for k, v in trainer.last.items():
+                        if torch.is_tensor(v) and v.numel() <= 2 and not bool(torch.isfinite(v).all()):
+                            raise RuntimeError("stage %d: %s is not finite after the timed iterations: %s" % (s, k, v))
+
             n = len(built)
         runner = Runner()
 
@@ -301,6 +307,9 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     ops.set_kernel_timer(None)
+    # outside the timed region: the iterations just timed must have produced finite losses (a fast run that trained
+    # NaNs - as hipGraph replays once did, DESIGN.md section 4 - is not a measurement)
+    runner.check_finite()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

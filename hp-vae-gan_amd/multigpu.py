@@ -554,8 +554,17 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         def timed_stage(self, idx):
             s, trainer, real, real_zero = built[idx]
             if trainer is not None:
-                trainer.step(real, real_zero)
+                self.last[s] = trainer.step(real, real_zero)
             return s
+
+        last = {}
+
+        def check_finite(self):
+            for s, out in self.last.items():
+                for k, v in (out or {}).items():
+                    t = v if torch.is_tensor(v) else torch.tensor(float(v))
+                    if t.numel() <= 2 and not bool(torch.isfinite(t).all()):
+                        raise RuntimeError("stage %d: %s is not finite after the timed iterations: %s" % (s, k, v))
 
     return Runner()
 

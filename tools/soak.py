@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
+bench.CONFIG = os.environ.get("HPVG_SOAK_CONFIG", "video")   # "image": the 2-D path (BASELINE configs[1])
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 stages = [int(a) for a in sys.argv[3:]] or [2, 4, 6]
