@@ -558,6 +558,7 @@ def build_bench_runner(make_opt, stages, device, rank, world):
             return s
 
         last = {}
+        items = built      # [(stage, trainer or None, real, real_zero)]
 
         def check_finite(self):
             for s, out in self.last.items():
