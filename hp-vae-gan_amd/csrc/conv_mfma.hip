@@ -23,6 +23,7 @@
 // (tap, m-tile); all workgroups read the same 442 KB so it stays L2 resident.
 // Accumulation is exact fp32 (v_mfma_f32_32x32x2_f32 == chain of fmaf).
 #include "hpvg_common.h"
+#include "hpvg.h"
 #include <stdlib.h>
 
 namespace {

@@ -16,6 +16,7 @@
 // The dY tile and the halo'd X tile of one time plane are staged in LDS with odd row strides so
 // that the 32 lanes of a half wave (32 different channels, same position) hit 32 different banks.
 #include "hpvg_common.h"
+#include "hpvg.h"
 
 namespace {
 

@@ -4,6 +4,7 @@
 // Reductions accumulate short fp32 runs per thread, then combine in fp64 in a fixed order
 // (two-stage: per-block partials -> one finishing block), so results are run-to-run identical.
 #include "hpvg_common.h"
+#include "hpvg.h"
 
 namespace {
 
@@ -544,16 +545,18 @@ __device__ __forceinline__ double block1024_sum(double v, double* sh) {
   return t;
 }
 
-__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ w, float* __restrict__ u,
+__device__ __forceinline__ void sn_power_iter_body(const float* __restrict__ w, float* __restrict__ u,
                                                               float* __restrict__ v, float* __restrict__ sigma_out,
                                                               float* __restrict__ inv_sigma_out, int Co, int K, int do_iter,
-                                                              float eps, float* __restrict__ wv_ws, float* __restrict__ uv_copy) {
+                                                              float eps, float* __restrict__ wv_ws, float* __restrict__ uv_copy,
+                                                              float* __restrict__ w_eff) {
   // The whole power iteration is one dependent chain on ONE workgroup (442 KB of weights): what it costs is memory
   // latency, so the two matrix-vector products read W as float4 with every thread's loads independent of each other.
   __shared__ double sh[16];
   __shared__ float su[1024];
   __shared__ float4 part[1024];
   __shared__ float4 sv4[1024];
+  __shared__ float s_sigma;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int K4 = K >> 2;
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
   if (tid == 0) {
     sigma_out[0] = (float)sig;
     inv_sigma_out[0] = (float)(1.0 / sig);
+    s_sigma = (float)sig;
   }
   if (uv_copy) {  // the (u, v) this sigma belongs to, for the backward (later forwards overwrite the buffers)
     for (int o = tid; o < Co; o += 1024) uv_copy[o] = su[o];
@@ -667,6 +671,48 @@ __global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __rest
       for (int k = tid; k < K; k += 1024) uv_copy[Co + k] = v[k];
     }
   }
+  if (w_eff) {  // weight = weight_orig / sigma (the batched launch folds the division in: one workgroup per layer)
+    __syncthreads();
+    const float d = s_sigma;
+    const long n = (long)Co * K;
+    if (vec) {
+      const long n4 = n >> 2;
+      float4* o4 = reinterpret_cast<float4*>(w_eff);
+#pragma unroll 4
+      for (long i = tid; i < n4; i += 1024) {
+        const float4 x = w4[i];
+        o4[i] = make_float4(x.x / d, x.y / d, x.z / d, x.w / d);
+      }
+    } else {
+      for (long i = tid; i < n; i += 1024) w_eff[i] = w[i] / d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* __restrict__ w, float* __restrict__ u,
+                                                              float* __restrict__ v, float* __restrict__ sigma_out,
+                                                              float* __restrict__ inv_sigma_out, int Co, int K, int do_iter,
+                                                              float eps, float* __restrict__ wv_ws, float* __restrict__ uv_copy) {
+  sn_power_iter_body(w, u, v, sigma_out, inv_sigma_out, Co, K, do_iter, eps, wv_ws, uv_copy, nullptr);
+}
+
+// All spectral-norm layers of a network in ONE launch, one workgroup per layer (they are independent): the six power
+// iterations of a discriminator forward run side by side instead of as six ~19 us single-workgroup launches in a row,
+// and each workgroup also writes weight = weight_orig / sigma.
+struct SnBatchArgs {
+  const float* w[HPVG_SN_BATCH_MAX];
+  float* u[HPVG_SN_BATCH_MAX];
+  float* v[HPVG_SN_BATCH_MAX];
+  float* sig[HPVG_SN_BATCH_MAX];      // sigma, 1/sigma (2 floats)
+  float* uv_copy[HPVG_SN_BATCH_MAX];
+  float* w_eff[HPVG_SN_BATCH_MAX];
+  float* wv_ws[HPVG_SN_BATCH_MAX];
+  int Co[HPVG_SN_BATCH_MAX], K[HPVG_SN_BATCH_MAX];
+};
+__global__ __launch_bounds__(1024) void sn_power_iter_batch_kernel(const SnBatchArgs a, int do_iter, float eps) {
+  const int i = blockIdx.x;
+  sn_power_iter_body(a.w[i], a.u[i], a.v[i], a.sig[i], a.sig[i] + 1, a.Co[i], a.K[i], do_iter, eps, a.wv_ws[i], a.uv_copy[i],
+                     a.w_eff[i]);
 }
 
 // backward of W = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
@@ -1066,6 +1112,25 @@ int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, flo
   return hpvg_launch_status();
 }
 size_t hpvg_sn_bwd_ws_bytes(int Co, int K) { return (size_t)hpvg_cdiv((long)Co * K, SN_CHUNK) * sizeof(double); }
+// n <= HPVG_SN_BATCH_MAX layers at once; arrays of n device pointers / sizes on the HOST (copied into the kernel arguments)
+// sig[i]: 2 floats (sigma, 1/sigma); uv_copy[i]: Co+K floats or NULL; w_eff[i]: Co*K floats; ws: sum(Co) floats
+int hpvg_sn_power_iter_batch_f32(int n, const float* const* w, float* const* u, float* const* v, float* const* sig,
+                                 float* const* uv_copy, float* const* w_eff, const int* Co, const int* K, int do_iter, float eps,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > HPVG_SN_BATCH_MAX || !w || !u || !v || !sig || !w_eff || !Co || !K || !ws) return HPVG_ERR_ARG;
+  SnBatchArgs a;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !u[i] || !v[i] || !sig[i] || !w_eff[i] || Co[i] < 1 || Co[i] > 1024 || K[i] < 1) return HPVG_ERR_ARG;
+    a.w[i] = w[i]; a.u[i] = u[i]; a.v[i] = v[i]; a.sig[i] = sig[i]; a.uv_copy[i] = uv_copy ? uv_copy[i] : nullptr;
+    a.w_eff[i] = w_eff[i]; a.Co[i] = Co[i]; a.K[i] = K[i];
+    a.wv_ws[i] = (float*)ws + off;
+    off += (size_t)Co[i];
+  }
+  if (ws_bytes < off * sizeof(float)) return HPVG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(sn_power_iter_batch_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, a, do_iter, eps);
+  return hpvg_launch_status();
+}
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
                     int accumulate, void* ws, size_t ws_bytes, int Co, int K, void* stream) {
   if (!dweff || !worig || !u || !v || !sigma || !dworig || !ws || Co < 1 || K < 1) return HPVG_ERR_ARG;

@@ -10,6 +10,7 @@
 // uint8 level when `quantize` is set (cv2.resize returns uint8), so single pixels can differ from cv2 by one level.
 // cv2 is not installed in the build image: PARITY UNPINNED against the reference's decoder/resizer.
 #include "hpvg_common.h"
+#include "hpvg.h"
 
 namespace {
 

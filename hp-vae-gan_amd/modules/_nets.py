@@ -84,11 +84,26 @@ class SNConv(nn.Module):
 
     halo = None  # as Conv.halo
 
-    def forward(self, x, act=False):
-        w = self.effective_weight()
+    def forward(self, x, act=False, weight=None):
+        """weight: the effective weight when the caller computed it for all of its spectral-norm layers at once
+        (sn_weights below); None: this layer runs its own power iteration."""
+        w = weight if weight is not None else self.effective_weight()
         if self.halo is not None:
             return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act))
         return ops.Conv.apply(x, w, self.bias, act)
+
+
+def sn_weights(convs):
+    """Effective weights of a list of SNConv layers through ONE launch (ops.SpectralNormWeightBatch): the same arithmetic
+    and buffer updates as calling effective_weight() on each, in order."""
+    out = []
+    for i in range(0, len(convs), ops.SN_BATCH_MAX):
+        part = convs[i:i + ops.SN_BATCH_MAX]
+        args = []
+        for m in part:
+            args += [m.weight_orig, m.weight_u, m.weight_v]
+        out += list(ops.SpectralNormWeightBatch.apply(part[0].training, 1e-12, *args))
+    return out
 
 
 class BatchNorm(nn.Module):
@@ -175,8 +190,8 @@ class ConvBlockSN(nn.Module):
         self.conv = SNConv(dims, in_channel, out_channel, ker_size, padding, stride)
         self.act = act
 
-    def forward(self, x):
-        return self.conv(x, act=self.act is not None)
+    def forward(self, x, weight=None):
+        return self.conv(x, act=self.act is not None, weight=weight)
 
 
 class FeatureExtractor(nn.Sequential):
@@ -190,6 +205,12 @@ class FeatureExtractor(nn.Sequential):
         for i in range(num_blocks - 1):
             self.add_module('conv_block_{}'.format(i + 1), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
         self.add_module('conv_block_{}'.format(num_blocks), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
+
+    def forward(self, x):
+        blocks = list(self)
+        for blk, w in zip(blocks, sn_weights([b.conv for b in blocks])):   # all power iterations in one launch
+            x = blk(x, weight=w)
+        return x
 
 
 class EncodeVAE(nn.Module):
@@ -236,7 +257,10 @@ class WDiscriminator(nn.Module):
         self.tail = Conv(dims, N, 1, opt.ker_size, 1, 1)
 
     def forward(self, x):
-        return self.tail(self.body(self.head(x)))
+        blocks = [self.head] + list(self.body)
+        for blk, w in zip(blocks, sn_weights([b.conv for b in blocks])):   # all power iterations in one launch
+            x = blk(x, weight=w)
+        return self.tail(x)
 
 
 class GeneratorHPVAEGAN(nn.Module):

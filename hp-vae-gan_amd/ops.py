@@ -472,6 +472,63 @@ class SpectralNormWeight(Function):
         return (None if slot is not None else out), None, None, None, None
 
 
+SN_BATCH_MAX = 8
+
+
+class SpectralNormWeightBatch(Function):
+    """SpectralNormWeight for up to 8 independent layers in ONE launch (one workgroup per layer: power iteration, sigma,
+    the (u, v) copy for the backward and weight = weight_orig / sigma): the spectral-norm convs of a network all need
+    their weight at the start of a forward, and six ~19 us single-workgroup launches in a row are pure latency.
+    apply(do_iter, eps, w1, u1, v1, w2, u2, v2, ...) -> (weight1, weight2, ...).  The backward runs per layer (the
+    gradients arrive layer by layer) with the same kernels as SpectralNormWeight."""
+
+    @staticmethod
+    def forward(ctx, do_iter, eps, *tensors):
+        n = len(tensors) // 3
+        assert 1 <= n <= SN_BATCH_MAX and len(tensors) == 3 * n
+        ws_orig = [_c(tensors[3 * i]) for i in range(n)]
+        us = [tensors[3 * i + 1] for i in range(n)]
+        vs = [tensors[3 * i + 2] for i in range(n)]
+        dev = ws_orig[0].device
+        Cos = [w.shape[0] for w in ws_orig]
+        Ks = [w.numel() // w.shape[0] for w in ws_orig]
+        sig = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        need = [w.requires_grad for w in ws_orig]
+        uvs = [torch.empty(Cos[i] + Ks[i], dtype=torch.float32, device=dev) if need[i] else None for i in range(n)]
+        outs = [torch.empty_like(w) for w in ws_orig]
+        ws = workspace(4 * sum(Cos), dev)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        call("hpvg_sn_power_iter_batch_f32", n, PA(*[ptr(w) for w in ws_orig]), PA(*[ptr(u) for u in us]), PA(*[ptr(v) for v in vs]),
+             PA(*[ptr(sig[i]) for i in range(n)]), PA(*[ptr(t) for t in uvs]), PA(*[ptr(o) for o in outs]), IA(*Cos), IA(*Ks),
+             1 if do_iter else 0, float(eps), ptr(ws), ctypes.c_size_t(ws.numel()), stream())
+        ctx.n = n
+        ctx.save_for_backward(sig, *ws_orig, *uvs)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dws):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        sig, ws_orig, uvs = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        grads = [None, None]
+        for i in range(n):
+            g = None
+            if dws[i] is not None and ctx.needs_input_grad[2 + 3 * i]:
+                w_orig, uv = ws_orig[i], uvs[i]
+                dw = _c(dws[i])
+                Co = w_orig.shape[0]
+                K = w_orig.numel() // Co
+                slot = grad_slot(w_orig)
+                out = slot if slot is not None else torch.empty_like(w_orig)
+                ws = workspace(call("hpvg_sn_bwd_ws_bytes", Co, K), dw.device)
+                call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(uv[:Co]), ptr(uv[Co:]), ptr(sig[i, 0:1]), ptr(out),
+                     1 if slot is not None else 0, ptr(ws), ctypes.c_size_t(ws.numel()), Co, K, stream())
+                g = None if slot is not None else out
+            grads += [g, None, None]
+        return tuple(grads)
+
+
 # ------------------------------------------------------------------------------------------ generator glue
 class TanhRes(Function):
     """y = tanh(x + res)  (res optional): networks_3d.py:377 (vae_out) and :404 (residual refinement)."""

@@ -131,6 +131,13 @@ int hpvg_frames_resize_norm_u8_f32(const unsigned char* src, float* dst, int N, 
 /* ---- spectral norm (nn.utils.spectral_norm, networks_3d.py:63): one power iteration, sigma, 1/sigma; backward through sigma */
 int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, float* inv_sigma, float* uv_copy, int Co, int K,
                            int do_iter, float eps, void* ws, size_t ws_bytes, void* stream);
+/* the same for n <= HPVG_SN_BATCH_MAX independent layers in one launch (one workgroup per layer, e.g. the six SN convs of
+ * WDiscriminator3D at the start of a forward), also writing w_eff[i] = w[i] / sigma_i.  The pointer / size arrays live on
+ * the host; sig[i] -> 2 floats (sigma, 1/sigma); uv_copy may be NULL or hold NULLs; ws: sum(Co) floats. */
+#define HPVG_SN_BATCH_MAX 8
+int hpvg_sn_power_iter_batch_f32(int n, const float* const* w, float* const* u, float* const* v, float* const* sig,
+                                 float* const* uv_copy, float* const* w_eff, const int* Co, const int* K, int do_iter, float eps,
+                                 void* ws, size_t ws_bytes, void* stream);
 /* out = x / s[0]: weight = weight_orig / sigma (torch SpectralNorm.compute_weight) */
 int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream);
 /* dworig (+)= dweff/sigma - (sum(dweff .* worig)/sigma^2) u v^T  (backward of weight_orig -> weight) */
