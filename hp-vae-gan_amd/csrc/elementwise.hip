@@ -1111,6 +1111,83 @@ int hpvg_sn_power_iter_f32(const float* w, float* u, float* v, float* sigma, flo
                      eps, (float*)ws, uv_copy);
   return hpvg_launch_status();
 }
+// batched over layers: grid (chunks of the largest layer, n layers)
+struct SnBwdBatchArgs {
+  const float* dweff[HPVG_SN_BATCH_MAX];
+  const float* worig[HPVG_SN_BATCH_MAX];
+  const float* uv[HPVG_SN_BATCH_MAX];      // u (Co) then v (K)
+  const float* sigma[HPVG_SN_BATCH_MAX];
+  float* dworig[HPVG_SN_BATCH_MAX];
+  double* part[HPVG_SN_BATCH_MAX];
+  int Co[HPVG_SN_BATCH_MAX], K[HPVG_SN_BATCH_MAX], accumulate[HPVG_SN_BATCH_MAX], vec[HPVG_SN_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void sn_bwd_dot_batch_kernel(const SnBwdBatchArgs a) {
+  __shared__ double sh[4];
+  const int i = blockIdx.y;
+  const long n = (long)a.Co[i] * a.K[i];
+  const long lo = (long)blockIdx.x * SN_CHUNK;
+  if (lo >= n) return;
+  const long hi = lo + SN_CHUNK < n ? lo + SN_CHUNK : n;
+  const float* dweff = a.dweff[i];
+  const float* worig = a.worig[i];
+  double acc = 0.0;
+  if (a.vec[i]) {
+    const float4* a4 = reinterpret_cast<const float4*>(dweff);
+    const float4* b4 = reinterpret_cast<const float4*>(worig);
+#pragma unroll 4
+    for (long j = (lo >> 2) + threadIdx.x; j < (hi >> 2); j += 256) {
+      const float4 x = a4[j], y = b4[j];
+      acc += (double)x.x * y.x + (double)x.y * y.y + (double)x.z * y.z + (double)x.w * y.w;
+    }
+  } else {
+    for (long j = lo + threadIdx.x; j < hi; j += 256) acc += (double)dweff[j] * worig[j];
+  }
+  const double tot = hpvg_block_sum_d(acc, sh);
+  if (threadIdx.x == 0) a.part[i][blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void sn_bwd_apply_batch_kernel(const SnBwdBatchArgs a) {
+  const int i = blockIdx.y;
+  const int Co = a.Co[i], K = a.K[i];
+  const long n = (long)Co * K;
+  const long lo = (long)blockIdx.x * SN_CHUNK;
+  if (lo >= n) return;
+  const long hi = lo + SN_CHUNK < n ? lo + SN_CHUNK : n;
+  const int nparts = (int)((n + SN_CHUNK - 1) / SN_CHUNK);
+  double dot = 0.0;
+  for (int g = 0; g < nparts; ++g) dot += a.part[i][g];
+  const float sg = a.sigma[i][0];
+  const float coef = (float)(dot / ((double)sg * sg));
+  const float* dweff = a.dweff[i];
+  const float* u = a.uv[i];
+  const float* v = a.uv[i] + Co;
+  float* dworig = a.dworig[i];
+  const int accumulate = a.accumulate[i];
+  if (a.vec[i]) {
+    const float4* a4 = reinterpret_cast<const float4*>(dweff);
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    float4* o4 = reinterpret_cast<float4*>(dworig);
+    const int K4 = K >> 2;
+#pragma unroll 4
+    for (long j = (lo >> 2) + threadIdx.x; j < (hi >> 2); j += 256) {
+      const int o = (int)(j / K4), c = (int)(j - (long)o * K4);
+      const float4 x = a4[j], y = v4[c];
+      const float cu = coef * u[o];
+      float4 t = make_float4(x.x / sg - cu * y.x, x.y / sg - cu * y.y, x.z / sg - cu * y.z, x.w / sg - cu * y.w);
+      if (accumulate) {
+        const float4 p = o4[j];
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      o4[j] = t;
+    }
+  } else {
+    for (long j = lo + threadIdx.x; j < hi; j += 256) {
+      const int o = (int)(j / K), k = (int)(j - (long)o * K);
+      const float t = dweff[j] / sg - coef * u[o] * v[k];
+      dworig[j] = accumulate ? dworig[j] + t : t;
+    }
+  }
+}
+
 size_t hpvg_sn_bwd_ws_bytes(int Co, int K) { return (size_t)hpvg_cdiv((long)Co * K, SN_CHUNK) * sizeof(double); }
 // n <= HPVG_SN_BATCH_MAX layers at once; arrays of n device pointers / sizes on the HOST (copied into the kernel arguments)
 // sig[i]: 2 floats (sigma, 1/sigma); uv_copy[i]: Co+K floats or NULL; w_eff[i]: Co*K floats; ws: sum(Co) floats
@@ -1129,6 +1206,33 @@ int hpvg_sn_power_iter_batch_f32(int n, const float* const* w, float* const* u, 
   }
   if (ws_bytes < off * sizeof(float)) return HPVG_ERR_WORKSPACE;
   hipLaunchKernelGGL(sn_power_iter_batch_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, a, do_iter, eps);
+  return hpvg_launch_status();
+}
+// the backward of n <= HPVG_SN_BATCH_MAX layers in two launches; host arrays as in hpvg_sn_power_iter_batch_f32; uv[i] = the
+// (u, v) copy of the forward (Co + K floats); ws: sum over layers of hpvg_sn_bwd_ws_bytes
+int hpvg_sn_bwd_batch_f32(int n, const float* const* dweff, const float* const* worig, const float* const* uv,
+                          const float* const* sigma, float* const* dworig, const int* accumulate, const int* Co, const int* K,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (n < 1 || n > HPVG_SN_BATCH_MAX || !dweff || !worig || !uv || !sigma || !dworig || !accumulate || !Co || !K || !ws)
+    return HPVG_ERR_ARG;
+  SnBwdBatchArgs a;
+  size_t off = 0;
+  int gmax = 1;
+  for (int i = 0; i < n; ++i) {
+    if (!dweff[i] || !worig[i] || !uv[i] || !sigma[i] || !dworig[i] || Co[i] < 1 || K[i] < 1) return HPVG_ERR_ARG;
+    const int G = (int)hpvg_cdiv((long)Co[i] * K[i], SN_CHUNK);
+    if (G > gmax) gmax = G;
+    a.dweff[i] = dweff[i]; a.worig[i] = worig[i]; a.uv[i] = uv[i]; a.sigma[i] = sigma[i]; a.dworig[i] = dworig[i];
+    a.Co[i] = Co[i]; a.K[i] = K[i]; a.accumulate[i] = accumulate[i];
+    a.vec[i] = (K[i] & 3) == 0 && (Co[i] & 3) == 0 &&
+               (((size_t)dweff[i] | (size_t)worig[i] | (size_t)uv[i] | (size_t)dworig[i]) & 15) == 0;
+    a.part[i] = (double*)((char*)ws + off);
+    off += (size_t)G * sizeof(double);
+  }
+  if (ws_bytes < off) return HPVG_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_bwd_dot_batch_kernel, dim3(gmax, n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(sn_bwd_apply_batch_kernel, dim3(gmax, n), dim3(256), 0, s, a);
   return hpvg_launch_status();
 }
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,

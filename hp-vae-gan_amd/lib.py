@@ -69,6 +69,7 @@ _SIGS = {
     "hpvg_sn_power_iter_f32": [P, P, P, P, P, P, I, I, I, F, P, Z, P],
     "hpvg_div_scalar_f32": [P, P, P, L, P],
     "hpvg_sn_power_iter_batch_f32": [I, P, P, P, P, P, P, P, P, I, F, P, Z, P],
+    "hpvg_sn_bwd_batch_f32": [I, P, P, P, P, P, P, P, P, P, Z, P],
     "hpvg_sn_bwd_ws_bytes": [I, I],
     "hpvg_sn_bwd_f32": [P, P, P, P, P, P, I, P, Z, I, I, P],
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],

@@ -512,20 +512,25 @@ class SpectralNormWeightBatch(Function):
         saved = ctx.saved_tensors
         sig, ws_orig, uvs = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
         grads = [None, None]
+        live = [i for i in range(n) if dws[i] is not None and ctx.needs_input_grad[2 + 3 * i]]
+        res = {}
+        if live:
+            m = len(live)
+            dev = dws[live[0]].device
+            dwc = [_c(dws[i]) for i in live]
+            slots = [grad_slot(ws_orig[i]) for i in live]
+            outs = [sl if sl is not None else torch.empty_like(ws_orig[i]) for sl, i in zip(slots, live)]
+            Cos = [ws_orig[i].shape[0] for i in live]
+            Ks = [ws_orig[i].numel() // ws_orig[i].shape[0] for i in live]
+            ws = workspace(sum(call("hpvg_sn_bwd_ws_bytes", c, k) for c, k in zip(Cos, Ks)), dev)
+            PA, IA = ctypes.c_void_p * m, ctypes.c_int * m
+            call("hpvg_sn_bwd_batch_f32", m, PA(*[ptr(t) for t in dwc]), PA(*[ptr(ws_orig[i]) for i in live]),
+                 PA(*[ptr(uvs[i]) for i in live]), PA(*[ptr(sig[i, 0:1]) for i in live]), PA(*[ptr(o) for o in outs]),
+                 IA(*[1 if sl is not None else 0 for sl in slots]), IA(*Cos), IA(*Ks), ptr(ws), ctypes.c_size_t(ws.numel()), stream())
+            for i, sl, o in zip(live, slots, outs):
+                res[i] = None if sl is not None else o
         for i in range(n):
-            g = None
-            if dws[i] is not None and ctx.needs_input_grad[2 + 3 * i]:
-                w_orig, uv = ws_orig[i], uvs[i]
-                dw = _c(dws[i])
-                Co = w_orig.shape[0]
-                K = w_orig.numel() // Co
-                slot = grad_slot(w_orig)
-                out = slot if slot is not None else torch.empty_like(w_orig)
-                ws = workspace(call("hpvg_sn_bwd_ws_bytes", Co, K), dw.device)
-                call("hpvg_sn_bwd_f32", ptr(dw), ptr(w_orig), ptr(uv[:Co]), ptr(uv[Co:]), ptr(sig[i, 0:1]), ptr(out),
-                     1 if slot is not None else 0, ptr(ws), ctypes.c_size_t(ws.numel()), Co, K, stream())
-                g = None if slot is not None else out
-            grads += [g, None, None]
+            grads += [res.get(i), None, None]
         return tuple(grads)
 
 

@@ -142,6 +142,10 @@ int hpvg_sn_power_iter_batch_f32(int n, const float* const* w, float* const* u, 
 int hpvg_div_scalar_f32(const float* x, const float* s, float* out, long n, void* stream);
 /* dworig (+)= dweff/sigma - (sum(dweff .* worig)/sigma^2) u v^T  (backward of weight_orig -> weight) */
 size_t hpvg_sn_bwd_ws_bytes(int Co, int K);
+/* n layers in two launches (host arrays as above; uv[i] = the forward's (u, v) copy; ws: sum of hpvg_sn_bwd_ws_bytes) */
+int hpvg_sn_bwd_batch_f32(int n, const float* const* dweff, const float* const* worig, const float* const* uv,
+                          const float* const* sigma, float* const* dworig, const int* accumulate, const int* Co, const int* K,
+                          void* ws, size_t ws_bytes, void* stream);
 int hpvg_sn_bwd_f32(const float* dweff, const float* worig, const float* u, const float* v, const float* sigma, float* dworig,
                     int accumulate, void* ws, size_t ws_bytes, int Co, int K, void* stream);
 
