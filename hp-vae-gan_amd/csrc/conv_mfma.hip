@@ -606,6 +606,38 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   wp[idx] = val;
 }
 
+// the same for up to HPVG_PACK_BATCH_MAX weights of ONE layer shape in a single launch (blockIdx.y = item); flip per item
+struct PackBatchArgs {
+  const float* w[HPVG_PACK_BATCH_MAX];
+  float* wp[HPVG_PACK_BATCH_MAX];
+  int flip[HPVG_PACK_BATCH_MAX];
+};
+__global__ void conv_pack_batch_kernel(const PackBatchArgs a, int C, int taps, int CC, int nchunk, int mbtot, long total) {
+  // square layers only (Cin == Cout == C): the forward and the flipped pack then share every size
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int it = blockIdx.y;
+  const float* __restrict__ w = a.w[it];
+  const int transpose_flip = a.flip[it];
+  const int CP = CC / 2;
+  long r = idx;
+  const int cp = r % CP; r /= CP;
+  const int lane = r % 64; r /= 64;
+  const int mb = r % mbtot; r /= mbtot;
+  const int tap = r % taps; r /= taps;
+  const int ch = (int)r;
+  float val = 0.f;
+  if (ch < nchunk) {
+    const int o = mb * 32 + (lane & 31);
+    const int c = ch * CC + 2 * cp + (lane >> 5);
+    if (o < C && c < C) {
+      if (!transpose_flip) val = w[((long)o * C + c) * taps + tap];
+      else val = w[((long)c * C + o) * taps + (taps - 1 - tap)];
+    }
+  }
+  a.wp[it][idx] = val;
+}
+
 inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
 
 struct Plan {
@@ -873,6 +905,24 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
   const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
   hipLaunchKernelGGL(conv_pack_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
                      Cin_k, Cout_k, KT * 9, CC, nchunk, mbtot, transpose_flip, total);
+  return hpvg_launch_status();
+}
+
+// n <= HPVG_PACK_BATCH_MAX weights of one SQUARE layer shape (C -> C, C > 4) packed in one launch; flip[i] selects the
+// backward-data pack for item i.  Host arrays of device pointers (copied into the kernel arguments).
+int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, void* stream) {
+  if (n < 1 || n > HPVG_PACK_BATCH_MAX || !w || !wp || !flip || C <= 4 || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  PackBatchArgs a;
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || !wp[i]) return HPVG_ERR_ARG;
+    a.w[i] = w[i]; a.wp[i] = wp[i]; a.flip[i] = flip[i];
+  }
+  const int CC = conv_cc(C);
+  const int nchunk = hpvg_cdiv(C, CC);
+  const int mbtot = hpvg_cdiv(C, 32);
+  const long total = (long)hpvg_conv_wpack_floats(C, C, KT);
+  hipLaunchKernelGGL(conv_pack_batch_kernel, dim3(hpvg_cdiv(total, 256), n), dim3(256), 0, (hipStream_t)stream, a, C, KT * 9, CC,
+                     nchunk, mbtot, total);
   return hpvg_launch_status();
 }
 

@@ -103,6 +103,7 @@ def sn_weights(convs):
         for m in part:
             args += [m.weight_orig, m.weight_u, m.weight_v]
         out += list(ops.SpectralNormWeightBatch.apply(part[0].training, 1e-12, *args))
+    ops.prepack_weights(out)   # forward and backward-data packs of the equal-shaped layers: one launch
     return out
 
 

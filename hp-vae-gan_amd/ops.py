@@ -124,6 +124,39 @@ def pack_weight(w, flip):
     return wp
 
 
+PACK_BATCH_MAX = 16
+
+
+def prepack_weights(ws, flips=(False, True)):
+    """Pack several weights of one square layer shape (C -> C, C > 4) in ONE launch and leave the results in the pack cache,
+    where the convs that follow find them (a discriminator forward packs its six spectral-norm weights twice each - forward
+    and backward-data - which used to be a dozen 4.5 us launches in a row).  Weights of other shapes are left to
+    pack_weight."""
+    items = []
+    for w in ws:
+        if w.dim() < 4 or w.shape[0] != w.shape[1] or w.shape[0] <= 4 or not w.is_contiguous():
+            continue
+        for f in flips:
+            key = (w.data_ptr(), bool(f), tuple(w.shape))
+            hit = _pack_cache.get(key)
+            if hit is None or hit[0] != w._version:
+                items.append((w, bool(f), key))
+    if not items:
+        return
+    shape = tuple(items[0][0].shape)
+    items = [it for it in items if tuple(it[0].shape) == shape][:PACK_BATCH_MAX]
+    C, KT = shape[0], _kt(shape)
+    nfl = call("hpvg_conv_wpack_floats", C, C, KT)
+    dev = items[0][0].device
+    wps = [torch.empty(nfl, dtype=torch.float32, device=dev) for _ in items]
+    m = len(items)
+    PA, IA = ctypes.c_void_p * m, ctypes.c_int * m
+    call("hpvg_conv_pack_weight_batch_f32", m, PA(*[ptr(it[0]) for it in items]), PA(*[ptr(t) for t in wps]),
+         IA(*[1 if it[1] else 0 for it in items]), C, KT, stream())
+    for (w, f, key), wp in zip(items, wps):
+        _pack_cache[key] = (w._version, w.detach(), wp)
+
+
 def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False):
     """y = conv(f(x), w) (+bias); flip=True runs the backward-data conv of the layer weight w."""
     x = _c(x)

@@ -36,6 +36,10 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 /* y = conv(f(x), wp) + bias; f = identity or LeakyReLU_opt(in_scale[c]*x + in_shift[c]) applied before zero padding
  * (fused BatchNorm-apply of the producing ConvBlock3D, networks_3d.py:54-55); out_lrelu: LeakyReLU(0.2) epilogue
  * (ConvBlock3DSN, networks_3d.py:59-70). bias may be NULL. */
+/* n <= HPVG_PACK_BATCH_MAX weights of one square layer shape (C -> C, C > 4) packed in one launch; flip[i] != 0: the
+ * backward-data pack of item i.  w / wp / flip: host arrays. */
+#define HPVG_PACK_BATCH_MAX 16
+int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, void* stream);
 /* ws (optional, may be NULL): scratch of hpvg_conv_fwd_ws_bytes() bytes for the stream-K schedule (512 persistent
  * workgroups share the (tile, channel-chunk) items evenly; tiles cut across workgroups pass through ws as partial sums
  * and are finished in fixed order).  Without it the same kernel runs one workgroup per tile: slower on grids of 1-5
