@@ -142,16 +142,18 @@ class BatchNorm(nn.Module):
     # image - is split over a process group (multigpu.py sets it on the BatchNorms of a sharded generator pass): the
     # statistics are over `total count` elements per channel (None: ranks x the local count); None = everything is local
     sync = None
+    # > 1 while the batch holds that many independent passes back to back (GeneratorHPVAEGAN.forward_pair): statistics per pass
+    groups = 1
 
     def forward(self, r, lrelu=True):
         if self.training:
-            self.pending_batches += 1
+            self.pending_batches += self.groups
             if self.sync is not None:
                 return ops.BNActSync.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
                                            self.eps, lrelu, self.sync[0], self.sync[1],
                                            self.sync[2] if len(self.sync) > 2 else None)
             return ops.BNAct.apply(r, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
-                                   lrelu)
+                                   lrelu, self.groups)
         with torch.no_grad():
             scale = self.weight / torch.sqrt(self.running_var + self.eps)
             shift = self.bias - self.running_mean * scale
@@ -322,6 +324,40 @@ class GeneratorHPVAEGAN(nn.Module):
         if noise_init is None:
             return x_prev_out, vae_out, (mu, logvar)
         return x_prev_out, vae_out
+
+    def forward_pair(self, video, noise_amp, noise_init):
+        """The two generator passes of a GAN-stage iteration - forward(video, amp, mode='rec') and forward(noise_init, amp,
+        noise_init=noise_init, mode='rand') (train_video.py:147,175) - as ONE pass over the concatenated batch: both use the
+        same weights and differ only in their inputs, in the level noise (zero for the rec half) and in BatchNorm's batch
+        (each half is normalised with its own statistics, running statistics updated rec first, then rand: BNAct groups).
+        Half the launches and twice the GEMM size where an iteration is a chain of small kernels.
+        Returns (generated, fake, vae_out of the rec half, (mu, logvar)); same random draws in the same order."""
+        assert self.training and self.slab is None
+        B = video.shape[0]
+        mu, logvar = self.encode(video)
+        z = torch.cat([self._reparameterize(mu, logvar), noise_init], dim=0)
+        bns = [m for part in (self.decoder, self.body) for m in part.modules() if isinstance(m, BatchNorm)]
+        for m in bns:
+            m.groups = 2
+        try:
+            vae_out = ops.TanhRes.apply(self.decoder(z), None)
+            x = vae_out
+            for idx, block in enumerate(self.body):
+                if self.opt.vae_levels == idx + 1 and not self.opt.train_all:
+                    x.detach_()
+                size = self._level_size(idx + 1)
+                if self.dims == 2 or self.opt.vae_levels <= idx + 1:   # levels where the rand pass injects noise
+                    ref = x.new_empty((B, x.shape[1], *size))
+                    noise = torch.cat([ref.new_empty(ref.shape).fill_(0.0), self._noise_like(ref)], dim=0)
+                    up, up_noisy = ops.UpsampleAC.apply(x, tuple(size), noise, float(noise_amp[idx + 1]))
+                else:
+                    up = up_noisy = ops.UpsampleAC.apply(x, tuple(size), None, 0.0)
+                x = ops.TanhRes.apply(block(up_noisy), up)
+        finally:
+            for m in bns:
+                m.groups = 1
+        generated, fake = ops.SplitBatch.apply(x, B)
+        return generated, fake, vae_out.detach()[:B], (mu, logvar)
 
     def _level_size(self, index):
         if self.dims == 3:

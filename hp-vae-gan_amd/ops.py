@@ -359,23 +359,32 @@ class ConvBwdWeight(Function):
 
 # ------------------------------------------------------------------------------------------ BatchNorm + LeakyReLU
 class BNAct(Function):
-    """h = LeakyReLU_opt(BatchNorm_train(r)) with running-stat update (ConvBlock3D: networks_3d.py:54-56)."""
+    """h = LeakyReLU_opt(BatchNorm_train(r)) with running-stat update (ConvBlock3D: networks_3d.py:54-56).
+
+    groups > 1: the batch holds `groups` independent passes of the network one after the other (the merged rec + rand
+    generator pass, GeneratorHPVAEGAN.forward_pair); every group is normalised with ITS OWN batch statistics and the
+    running statistics are updated once per group, in order - exactly what the separate passes would do.  The groups are
+    contiguous slices of r, so the same kernels run on offset pointers."""
 
     @staticmethod
-    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu):
+    def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu, groups=1):
         r = _c(r)
         B, C, T, H, W = geom(r)
         S = T * H * W
         dev = r.device
-        stats = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        assert B % groups == 0
+        Bg = B // groups
+        stats = torch.empty(groups, 4, C, dtype=torch.float32, device=dev)  # per group: mean, invstd, scale, shift
         nws = call("hpvg_bn_ws_bytes", C)
         ws = workspace(nws, dev)
         h = torch.empty_like(r)
-        call("hpvg_bn_train_fwd_f32", ptr(r), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-             float(momentum), float(eps), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(h),
-             1 if lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
+        for g in range(groups):
+            st = stats[g]
+            call("hpvg_bn_train_fwd_f32", ptr(r[g * Bg:(g + 1) * Bg]), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                 float(momentum), float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(h[g * Bg:(g + 1) * Bg]),
+                 1 if lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel()), Bg, C, ctypes.c_long(S), stream())
         ctx.save_for_backward(r, stats, gamma, beta)
-        ctx.lrelu = lrelu
+        ctx.lrelu, ctx.groups = lrelu, groups
         return h
 
     @staticmethod
@@ -386,18 +395,47 @@ class BNAct(Function):
         B, C, T, H, W = geom(r)
         S = T * H * W
         dev = r.device
+        groups = ctx.groups
+        Bg = B // groups
         dr = torch.empty_like(r)
         sg, sb = grad_slot(gamma), grad_slot(beta)
         direct = sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
         dgb = (sg, sb) if direct else torch.empty(2, C, dtype=torch.float32, device=dev)
         nws = call("hpvg_bn_ws_bytes", C)
         ws = workspace(nws, dev)
-        call("hpvg_bn_act_bwd_f32", ptr(dh), ptr(r), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-             1 if ctx.lrelu else 0, ptr(dr), ptr(dgb[0]), ptr(dgb[1]), 1 if direct else 0, ptr(ws), ctypes.c_size_t(ws.numel()),
-             B, C, ctypes.c_long(S), stream())
+        for g in range(groups):
+            st = stats[g]
+            sl = slice(g * Bg, (g + 1) * Bg)
+            call("hpvg_bn_act_bwd_f32", ptr(dh[sl]), ptr(r[sl]), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
+                 1 if ctx.lrelu else 0, ptr(dr[sl]), ptr(dgb[0]), ptr(dgb[1]), 1 if (direct or g > 0) else 0, ptr(ws),
+                 ctypes.c_size_t(ws.numel()), Bg, C, ctypes.c_long(S), stream())
         if direct:
-            return dr, None, None, None, None, None, None, None
-        return dr, dgb[0], dgb[1], None, None, None, None, None
+            return dr, None, None, None, None, None, None, None, None
+        return dr, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+class SplitBatch(Function):
+    """(x[:n], x[n:]) as two outputs.  torch's own slicing would do: but its backward builds the full-size gradient with
+    at::zeros + copy, i.e. a hipMemsetAsync, which must not appear in an iteration that may be captured into a hipGraph
+    (DESIGN.md section 4); this backward is one concatenation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x = _c(x)
+        ctx.n, ctx.shape = n, x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        n, shape = ctx.n, ctx.shape
+        if g0 is None and g1 is None:
+            return None, None
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = ref.new_empty((n,) + tuple(shape[1:])).fill_(0.0)
+        if g1 is None:
+            g1 = ref.new_empty((shape[0] - n,) + tuple(shape[1:])).fill_(0.0)
+        return torch.cat([g0, g1], dim=0), None
 
 
 class BNActSync(Function):

@@ -146,7 +146,12 @@ class StageTrainer:
             self.calibrate_noise_amp(real, real_zero)
 
         out = {}
-        generated, generated_vae, (mu, logvar) = netG(real_zero, opt.Noise_Amps, mode="rec")
+        merged = self.is_gan and getattr(opt, 'merge_passes', True) and hasattr(netG, 'forward_pair')
+        if merged:
+            # rec and rand pass in one (netG.forward_pair): same draws, same arithmetic per sample, half the launches
+            generated, fake, generated_vae, (mu, logvar) = netG.forward_pair(real_zero, opt.Noise_Amps, noise_init)
+        else:
+            generated, generated_vae, (mu, logvar) = netG(real_zero, opt.Noise_Amps, mode="rec")
         if not self.is_gan:
             rec_vae_loss = mse_loss(generated, real) + mse_loss(generated_vae, real_zero)
             kl_loss = kl_criterion(mu, logvar)
@@ -156,7 +161,8 @@ class StageTrainer:
             netD = self.netD
             self.arenaD.zero_grad()
             errD_real = wgan_mean(netD(real), -1.0)
-            fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
+            if not merged:
+                fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
             errD_fake = wgan_mean(netD(fake.detach()), 1.0)
             gradient_penalty = calc_gradient_penalty(netD, real, fake, opt.lambda_grad, opt.device, alpha=alpha)
             errD_total = errD_real + errD_fake + gradient_penalty
