@@ -21,7 +21,7 @@ for i, (s, e, n) in enumerate(rows):
         else:
             fix.append((e - s) / 1e3)
 print("kernel:", key, " launches:", len(main))
-edges = [0, 100, 300, 600, 1000, 1500, 1e9]
+edges = [0, 100, 300, 600, 1000, 1500, 2500, 1e9]  # 1.5-2.5 ms: the B = 2 finest-level launches (the roofline shape); above: B = 4 (merged generator pass)
 for lo, hi in zip(edges[:-1], edges[1:]):
     sel = [(m, f) for m, f in zip(main, fix) if lo <= m < hi]
     if sel:
