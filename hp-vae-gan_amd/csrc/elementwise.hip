@@ -397,6 +397,9 @@ __global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restric
   const float v = g[0] * coef;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v;
 }
+__global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = 0.f;
 }
@@ -1034,6 +1037,14 @@ int hpvg_sqsum_f32(const float* x, float* out, void* ws, size_t ws_bytes, long n
 int hpvg_fill_scaled_f32(const float* gout, float coef, float* out, long n, void* stream) {
   if (!gout || !out || n < 1) return HPVG_ERR_ARG;
   hipLaunchKernelGGL(fill_scaled_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gout, coef, out, n);
+  return hpvg_launch_status();
+}
+// dst = src (a KERNEL copy: hipMemcpyAsync becomes a memcpy node in a captured hipGraph - see hpvg_upsample_linear_ac_bwd_f32);
+// src == NULL: dst = 0
+int hpvg_copy_f32(const float* src, float* dst, long n, void* stream) {
+  if (!dst || n < 1) return HPVG_ERR_ARG;
+  if (src) hipLaunchKernelGGL(copy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  else hipLaunchKernelGGL(zero_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dst, n);
   return hpvg_launch_status();
 }
 // out = a + b

@@ -49,6 +49,7 @@ _SIGS = {
     "hpvg_bn_act_bwd_apply_f32": [P, P, P, P, P, P, I, P, F, P, I, I, L, P],
     "hpvg_lrelu_mask_mul_f32": [P, P, P, L, P],
     "hpvg_add_f32": [P, P, P, L, P],
+    "hpvg_copy_f32": [P, P, L, P],
     "hpvg_tanh_fwd_f32": [P, P, P, L, P],
     "hpvg_tanh_bwd_f32": [P, P, P, L, P],
     "hpvg_reparam_fwd_f32": [P, P, P, P, L, P],

@@ -335,7 +335,7 @@ class GeneratorHPVAEGAN(nn.Module):
         assert self.training and self.slab is None
         B = video.shape[0]
         mu, logvar = self.encode(video)
-        z = torch.cat([self._reparameterize(mu, logvar), noise_init], dim=0)
+        z = ops.Concat2.apply(self._reparameterize(mu, logvar), noise_init)
         bns = [m for part in (self.decoder, self.body) for m in part.modules() if isinstance(m, BatchNorm)]
         for m in bns:
             m.groups = 2
@@ -348,7 +348,7 @@ class GeneratorHPVAEGAN(nn.Module):
                 size = self._level_size(idx + 1)
                 if self.dims == 2 or self.opt.vae_levels <= idx + 1:   # levels where the rand pass injects noise
                     ref = x.new_empty((B, x.shape[1], *size))
-                    noise = torch.cat([ref.new_empty(ref.shape).fill_(0.0), self._noise_like(ref)], dim=0)
+                    noise = ops.concat_batch([B, self._noise_like(ref)])   # zero noise for the rec half
                     up, up_noisy = ops.UpsampleAC.apply(x, tuple(size), noise, float(noise_amp[idx + 1]))
                 else:
                     up = up_noisy = ops.UpsampleAC.apply(x, tuple(size), None, 0.0)

@@ -414,6 +414,41 @@ class BNAct(Function):
         return dr, dgb[0], dgb[1], None, None, None, None, None, None
 
 
+def concat_batch(parts, like=None):
+    """torch.cat(parts, dim=0) for contiguous fp32 tensors of equal trailing shape, with kernel copies: torch.cat (and
+    torch.zeros) may lower to hipMemcpyAsync / hipMemsetAsync, i.e. memcpy / memset NODES when the iteration is captured
+    into a hipGraph, and those are not reliably ordered on this runtime.  An entry that is an int n
+    stands for n zero samples."""
+    ref = like if like is not None else next(p for p in parts if torch.is_tensor(p))
+    tail = tuple(ref.shape[1:])
+    per = 1
+    for d in tail:
+        per *= int(d)
+    total = sum(p if isinstance(p, int) else p.shape[0] for p in parts)
+    out = torch.empty((total,) + tail, dtype=torch.float32, device=ref.device)
+    o = 0
+    for p in parts:
+        n = p if isinstance(p, int) else p.shape[0]
+        src = None if isinstance(p, int) else ptr(_c(p.detach()))
+        call("hpvg_copy_f32", src, ptr(out[o:o + n]), ctypes.c_long(n * per), stream())
+        o += n
+    return out
+
+
+class Concat2(Function):
+    """Differentiable concat_batch of two tensors (the latent batch of the merged generator pass)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.n = a.shape[0]
+        return concat_batch([a, b])
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return g[:ctx.n], g[ctx.n:]
+
+
 class SplitBatch(Function):
     """(x[:n], x[n:]) as two outputs.  torch's own slicing would do: but its backward builds the full-size gradient with
     at::zeros + copy, i.e. a hipMemsetAsync, which must not appear in an iteration that may be captured into a hipGraph
@@ -431,11 +466,7 @@ class SplitBatch(Function):
         if g0 is None and g1 is None:
             return None, None
         ref = g0 if g0 is not None else g1
-        if g0 is None:
-            g0 = ref.new_empty((n,) + tuple(shape[1:])).fill_(0.0)
-        if g1 is None:
-            g1 = ref.new_empty((shape[0] - n,) + tuple(shape[1:])).fill_(0.0)
-        return torch.cat([g0, g1], dim=0), None
+        return concat_batch([g0 if g0 is not None else n, g1 if g1 is not None else shape[0] - n], like=ref), None
 
 
 class BNActSync(Function):

@@ -98,6 +98,9 @@ int hpvg_lrelu_mask_mul_f32(const float* dy, const float* h, float* out, long n,
 /* ---- generator glue: tanh / residual (networks_3d.py:377,404), reparameterize (networks_3d.py:29-33) */
 /* out = a + b: residual add of the SinGAN baseline generator (networks_3d.py:319) */
 int hpvg_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+/* dst = src, or dst = 0 when src is NULL - as a kernel (concatenations / zero fills of an iteration that may be captured
+ * into a hipGraph must not become memcpy / memset nodes) */
+int hpvg_copy_f32(const float* src, float* dst, long n, void* stream);
 int hpvg_tanh_fwd_f32(const float* x, const float* res /*nullable*/, float* y, long n, void* stream);
 int hpvg_tanh_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream);
 int hpvg_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, long n, void* stream);
