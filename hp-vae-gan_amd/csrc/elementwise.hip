@@ -69,9 +69,12 @@ int reduce_scalar(const float* a, const float* b, long n, double scale, float* o
 template <int V>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int B, int C, long S, int nsplit,
                                                                 double* __restrict__ part) {
+  // grid.y = C * G: G independent groups of B samples each, back to back in x (G = 1: plain BatchNorm); partials [g*C + c]
   typedef typename HpvgVec<V>::type Vec;
   __shared__ double sh[4];
-  const int c = blockIdx.y, k = blockIdx.x;
+  const int cg = blockIdx.y, k = blockIdx.x;
+  const int g = cg / C, c = cg - g * C;
+  x += (long)g * B * C * S;
   const long SV = S / V;
   const long chunk = (SV + nsplit - 1) / nsplit;
   const long lo = (long)k * chunk, hi = (lo + chunk < SV) ? lo + chunk : SV;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   const double t1 = hpvg_block_sum_d(a1, sh);
   const double t2 = hpvg_block_sum_d(a2, sh);
   if (threadIdx.x == 0) {
-    part[((long)c * nsplit + k) * 2 + 0] = t1;
-    part[((long)c * nsplit + k) * 2 + 1] = t2;
+    part[((long)cg * nsplit + k) * 2 + 0] = t1;
+    part[((long)cg * nsplit + k) * 2 + 1] = t2;
   }
 }
 
@@ -154,14 +157,20 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                               float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                                              float* __restrict__ y, int C, long S, int lrelu) {
+                                                              float* __restrict__ y, int C, long S, int lrelu, int Bg, int G,
+                                                              int gstride) {
+  // G groups of Bg samples (statistics per group; `count` = elements per channel of ONE group; the *_out arrays of group g
+  // start gstride floats after those of group g-1).  Running statistics: one workgroup per channel applies the groups'
+  // updates one after the other, in order - what G separate BatchNorm calls would do.
   __shared__ float s_sc, s_sh;
   const int bc = blockIdx.y;
-  const int c = bc % C;
+  const int b = bc / C, c = bc - b * C;
+  const int g = b / Bg;
   if (threadIdx.x < 64) {
     const int k = threadIdx.x;
-    double s1 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 0] : 0.0;
-    double s2 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 1] : 0.0;
+    const long pc = (long)g * C + c;
+    double s1 = k < nsplit ? part[(pc * nsplit + k) * 2 + 0] : 0.0;
+    double s2 = k < nsplit ? part[(pc * nsplit + k) * 2 + 1] : 0.0;
     s1 = hpvg_wave_sum_d(s1);
     s2 = hpvg_wave_sum_d(s2);
     if (k == 0) {
@@ -169,17 +178,30 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
       double var = s2 / count - mean * mean;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-      const float sc = g * invstd;
+      const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+      const float sc = gm * invstd;
       const float sh = bt - (float)mean * sc;
       s_sc = sc;
       s_sh = sh;
-      if (blockIdx.x == 0 && bc == c) {
-        mean_out[c] = (float)mean;
-        invstd_out[c] = invstd;
-        scale_out[c] = sc;
-        shift_out[c] = sh;
-        if (running_mean) {
+      if (blockIdx.x == 0 && b == g * Bg) {
+        const long o = (long)g * gstride + c;
+        mean_out[o] = (float)mean;
+        invstd_out[o] = invstd;
+        scale_out[o] = sc;
+        shift_out[o] = sh;
+      }
+    }
+    if (running_mean && blockIdx.x == 0 && b == 0) {
+      for (int gg = 0; gg < G; ++gg) {
+        const long qc = (long)gg * C + c;
+        double r1 = k < nsplit ? part[(qc * nsplit + k) * 2 + 0] : 0.0;
+        double r2 = k < nsplit ? part[(qc * nsplit + k) * 2 + 1] : 0.0;
+        r1 = hpvg_wave_sum_d(r1);
+        r2 = hpvg_wave_sum_d(r2);
+        if (k == 0) {
+          const double mean = r1 / count;
+          double var = r2 / count - mean * mean;
+          if (var < 0.0) var = 0.0;
           const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
           running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
           running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
@@ -221,14 +243,19 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    int B, int C, long S, int nsplit, int lrelu,
-                                                                   double* __restrict__ part) {
+                                                                   double* __restrict__ part, int gstride) {
+  // grid.y = C * G (groups as in bn_stats_partial_kernel; the statistics of group g start g * gstride floats further)
   typedef typename HpvgVec<V>::type Vec;
   __shared__ double sh[4];
-  const int c = blockIdx.y, k = blockIdx.x;
+  const int cg = blockIdx.y, k = blockIdx.x;
+  const int g = cg / C, c = cg - g * C;
+  dh += (long)g * B * C * S;
+  r += (long)g * B * C * S;
+  const long so = (long)g * gstride + c;
   const long SV = S / V;
   const long chunk = (SV + nsplit - 1) / nsplit;
   const long lo = (long)k * chunk, hi = (lo + chunk < SV) ? lo + chunk : SV;
-  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  const float mu = mean[so], is = invstd[so], sc = scale[so], sf = shift[so];
   double a1 = 0.0, a2 = 0.0;
   for (int b = 0; b < B; ++b) {
     const Vec* dp = reinterpret_cast<const Vec*>(dh + ((long)b * C + c) * S);
@@ -254,8 +281,8 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
   const double t1 = hpvg_block_sum_d(a1, sh);
   const double t2 = hpvg_block_sum_d(a2, sh);
   if (threadIdx.x == 0) {
-    part[((long)c * nsplit + k) * 2 + 0] = t1;
-    part[((long)c * nsplit + k) * 2 + 1] = t2;
+    part[((long)cg * nsplit + k) * 2 + 0] = t1;
+    part[((long)cg * nsplit + k) * 2 + 1] = t2;
   }
 }
 
@@ -304,27 +331,42 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_fused_kernel(const flo
                                                                         const double* __restrict__ part, int nsplit,
                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                         int accumulate, float* __restrict__ dr, int C, long S,
-                                                                        float inv_count, int lrelu) {
+                                                                        float inv_count, int lrelu, int Bg, int G, int gstride) {
   __shared__ float s_m1, s_m2;
   const int bc = blockIdx.y;
-  const int c = bc % C;
+  const int b = bc / C, c = bc - b * C;
+  const int g = b / Bg;
   if (threadIdx.x < 64) {
     const int k = threadIdx.x;
-    double s1 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 0] : 0.0;
-    double s2 = k < nsplit ? part[((long)c * nsplit + k) * 2 + 1] : 0.0;
+    const long pc = (long)g * C + c;
+    double s1 = k < nsplit ? part[(pc * nsplit + k) * 2 + 0] : 0.0;
+    double s2 = k < nsplit ? part[(pc * nsplit + k) * 2 + 1] : 0.0;
     s1 = hpvg_wave_sum_d(s1);
     s2 = hpvg_wave_sum_d(s2);
     if (k == 0) {
       s_m1 = (float)s1 * inv_count;
       s_m2 = (float)s2 * inv_count;
-      if (blockIdx.x == 0 && bc == c) {
-        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    }
+    if (blockIdx.x == 0 && b == 0) {  // dbeta / dgamma: the groups' sums added up in order by one workgroup per channel
+      float tb = 0.f, tg = 0.f;
+      for (int gg = 0; gg < G; ++gg) {
+        const long qc = (long)gg * C + c;
+        double r1 = k < nsplit ? part[(qc * nsplit + k) * 2 + 0] : 0.0;
+        double r2 = k < nsplit ? part[(qc * nsplit + k) * 2 + 1] : 0.0;
+        r1 = hpvg_wave_sum_d(r1);
+        r2 = hpvg_wave_sum_d(r2);
+        tb += (float)r1;
+        tg += (float)r2;
+      }
+      if (k == 0) {
+        dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+        dgamma[c] = accumulate ? dgamma[c] + tg : tg;
       }
     }
   }
   __syncthreads();
-  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  const long so = (long)g * gstride + c;
+  const float mu = mean[so], is = invstd[so], sc = scale[so], sf = shift[so];
   const float m1 = s_m1, m2 = s_m2;
   const float* dp = dh + (long)bc * S;
   const float* rp = r + (long)bc * S;
@@ -859,29 +901,50 @@ int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* bet
 // (statistics out, running-stat update) - hpvg_bn_train_stats_f32 + hpvg_affine_act_f32 without the finalize launch.
 int hpvg_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, float* y, int lrelu,
-                          void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+                          int groups, void* ws, size_t ws_bytes, int B, int C, long S, void* stream) {
+  // groups > 1: the batch is `groups` independent passes of B / groups samples, normalised separately (running statistics
+  // updated once per group, in order); the statistics arrays of group g start 4 * C floats after those of group g - 1
+  // (layout [groups][mean, invstd, scale, shift][C])
   if (!x || !y || !mean || !invstd || !scale || !shift || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
-  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
-  const int ns = bn_nsplit(B, C, S);
+  if (groups < 1 || B % groups) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C * groups)) return HPVG_ERR_WORKSPACE;
+  const int Bg = B / groups;
+  const int gstride = 4 * C;
+  const int ns = bn_nsplit(Bg, C, S);
   hipStream_t s = (hipStream_t)stream;
-  switch (hpvg_vec_width(x, S)) {
-    case 4: hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
-    case 2: hipLaunchKernelGGL(bn_stats_partial_kernel<2>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws); break;
-    default: hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(ns, C), dim3(256), 0, s, x, B, C, S, ns, (double*)ws);
-  }
   if ((long)B * C * S > HPVG_BN_FUSE_MAX) {
-    // large tensors: tens of thousands of apply workgroups would each repeat the finalize prologue - three launches win
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)B * (double)S,
-                       eps, momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
-    int nbx = hpvg_cdiv(S, 256 * 4);
-    if (nbx > 1024) nbx = 1024;
-    hipLaunchKernelGGL(affine_act_kernel, dim3(nbx, B * C), dim3(256), 0, s, x, (const float*)scale, (const float*)shift, y, C, S,
-                       lrelu);
+    // large tensors: tens of thousands of apply workgroups would each repeat the finalize prologue - three launches (per
+    // group) win
+    for (int g = 0; g < groups; ++g) {
+      const float* xg = x + (long)g * Bg * C * S;
+      float* yg = y + (long)g * Bg * C * S;
+      switch (hpvg_vec_width(xg, S)) {
+        case 4: hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(ns, C), dim3(256), 0, s, xg, Bg, C, S, ns, (double*)ws); break;
+        case 2: hipLaunchKernelGGL(bn_stats_partial_kernel<2>, dim3(ns, C), dim3(256), 0, s, xg, Bg, C, S, ns, (double*)ws); break;
+        default: hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(ns, C), dim3(256), 0, s, xg, Bg, C, S, ns, (double*)ws);
+      }
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, (double)Bg * (double)S,
+                         eps, momentum, gamma, beta, running_mean, running_var, mean + g * gstride, invstd + g * gstride,
+                         scale + g * gstride, shift + g * gstride);
+      int nbx = hpvg_cdiv(S, 256 * 4);
+      if (nbx > 1024) nbx = 1024;
+      hipLaunchKernelGGL(affine_act_kernel, dim3(nbx, Bg * C), dim3(256), 0, s, xg, (const float*)(scale + g * gstride),
+                         (const float*)(shift + g * gstride), yg, C, S, lrelu);
+    }
     return hpvg_launch_status();
   }
+  const long gsz = (long)Bg * C * S;
+  int vw = 4;
+  for (int g = 0; g < groups; ++g) { const int v = hpvg_vec_width(x + g * gsz, S); if (v < vw) vw = v; }
+  switch (vw) {
+    case 4: hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(ns, C * groups), dim3(256), 0, s, x, Bg, C, S, ns, (double*)ws); break;
+    case 2: hipLaunchKernelGGL(bn_stats_partial_kernel<2>, dim3(ns, C * groups), dim3(256), 0, s, x, Bg, C, S, ns, (double*)ws); break;
+    default: hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(ns, C * groups), dim3(256), 0, s, x, Bg, C, S, ns, (double*)ws);
+  }
   const int nbx = hpvg_cdiv(S, 256 * 16);
-  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, x, (const double*)ws, ns, (double)B * (double)S, eps,
-                     momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, y, C, S, lrelu);
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, x, (const double*)ws, ns, (double)Bg * (double)S, eps,
+                     momentum, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, y, C, S, lrelu, Bg, groups,
+                     gstride);
   return hpvg_launch_status();
 }
 
@@ -919,9 +982,9 @@ int hpvg_bn_act_bwd_sums_f32(const float* dh, const float* r, const float* mean,
   hipStream_t s = (hipStream_t)stream;
   {
     const int vw = hpvg_vec_width(dh, S) < hpvg_vec_width(r, S) ? hpvg_vec_width(dh, S) : hpvg_vec_width(r, S);
-    if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws);
-    else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws);
-    else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws);
+    if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws, 0);
+    else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws, 0);
+    else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, (double*)ws, 0);
   }
   hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, sums);
   return hpvg_launch_status();
@@ -949,32 +1012,49 @@ int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, 
 
 // dr, dgamma, dbeta of  h = lrelu?(BN_train(r))  given dh
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
-                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
+                        const float* shift, int lrelu, int groups, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
                         size_t ws_bytes, int B, int C, long S, void* stream) {
+  // groups: as in hpvg_bn_train_fwd_f32 (statistics layout [groups][4][C]); dgamma / dbeta are summed over the groups
   if (!dh || !r || !mean || !invstd || !scale || !shift || !dr || !dgamma || !dbeta || !ws) return HPVG_ERR_ARG;
-  if (ws_bytes < hpvg_bn_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
-  const int ns = bn_nsplit(B, C, S);
+  if (groups < 1 || B % groups) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_ws_bytes(C * groups)) return HPVG_ERR_WORKSPACE;
+  const int Bg = B / groups;
+  const int gstride = 4 * C;
+  const int ns = bn_nsplit(Bg, C, S);
   hipStream_t s = (hipStream_t)stream;
   double* part = (double*)ws;
-  {
-    const int vw = hpvg_vec_width(dh, S) < hpvg_vec_width(r, S) ? hpvg_vec_width(dh, S) : hpvg_vec_width(r, S);
-    if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
-    else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
-    else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
-  }
+  const long gsz = (long)Bg * C * S;
   if ((long)B * C * S > HPVG_BN_FUSE_MAX) {
-    float* sums = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
-                       sums, accumulate);
-    int nbx = hpvg_cdiv(S, 256 * 4);
-    if (nbx > 1024) nbx = 1024;
-    hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
-                       (const float*)sums, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
+    float* sums = (float*)((char*)ws + (size_t)C * groups * 64 * 2 * sizeof(double));
+    for (int g = 0; g < groups; ++g) {
+      const float* dhg = dh + g * gsz;
+      const float* rg = r + g * gsz;
+      const float *mg = mean + g * gstride, *ig = invstd + g * gstride, *sg = scale + g * gstride, *fg = shift + g * gstride;
+      const int vw = hpvg_vec_width(dhg, S) < hpvg_vec_width(rg, S) ? hpvg_vec_width(dhg, S) : hpvg_vec_width(rg, S);
+      if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dhg, rg, mg, ig, sg, fg, Bg, C, S, ns, lrelu, part, 0);
+      else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dhg, rg, mg, ig, sg, fg, Bg, C, S, ns, lrelu, part, 0);
+      else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dhg, rg, mg, ig, sg, fg, Bg, C, S, ns, lrelu, part, 0);
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, dgamma, dbeta,
+                         sums, (accumulate || g > 0) ? 1 : 0);
+      int nbx = hpvg_cdiv(S, 256 * 4);
+      if (nbx > 1024) nbx = 1024;
+      hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3(nbx, Bg * C), dim3(256), 0, s, dhg, rg, mg, ig, sg, fg,
+                         (const float*)sums, dr + g * gsz, C, S, (float)(1.0 / ((double)Bg * (double)S)), lrelu);
+    }
     return hpvg_launch_status();
   }
+  int vw = 4;
+  for (int g = 0; g < groups; ++g) {
+    const int v = hpvg_vec_width(dh + g * gsz, S) < hpvg_vec_width(r + g * gsz, S) ? hpvg_vec_width(dh + g * gsz, S) : hpvg_vec_width(r + g * gsz, S);
+    if (v < vw) vw = v;
+  }
+  if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(ns, C * groups), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, Bg, C, S, ns, lrelu, part, gstride);
+  else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<2>, dim3(ns, C * groups), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, Bg, C, S, ns, lrelu, part, gstride);
+  else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(ns, C * groups), dim3(256), 0, s, dh, r, mean, invstd, scale, shift, Bg, C, S, ns, lrelu, part, gstride);
   const int nbx = hpvg_cdiv(S, 256 * 16);
   hipLaunchKernelGGL(bn_lrelu_bwd_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
-                     (const double*)part, ns, dgamma, dbeta, accumulate, dr, C, S, (float)(1.0 / ((double)B * (double)S)), lrelu);
+                     (const double*)part, ns, dgamma, dbeta, accumulate, dr, C, S, (float)(1.0 / ((double)Bg * (double)S)), lrelu, Bg,
+                     groups, gstride);
   return hpvg_launch_status();
 }
 

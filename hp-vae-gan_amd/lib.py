@@ -41,8 +41,8 @@ _SIGS = {
     "hpvg_bn_ws_bytes": [I],
     "hpvg_bn_train_stats_f32": [P, P, P, P, P, F, F, P, P, P, P, P, Z, I, I, L, P],
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
-    "hpvg_bn_train_fwd_f32": [P, P, P, P, P, F, F, P, P, P, P, P, I, P, Z, I, I, L, P],
-    "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, P, P, P, I, P, Z, I, I, L, P],
+    "hpvg_bn_train_fwd_f32": [P, P, P, P, P, F, F, P, P, P, P, P, I, I, P, Z, I, I, L, P],
+    "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, I, P, P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_sums_f32": [P, P, P, Z, I, I, L, P],
     "hpvg_bn_finalize_f32": [P, D, P, P, P, P, F, F, P, P, P, P, I, P],
     "hpvg_bn_act_bwd_sums_f32": [P, P, P, P, P, P, I, P, P, Z, I, I, L, P],

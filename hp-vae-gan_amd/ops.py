@@ -375,14 +375,13 @@ class BNAct(Function):
         assert B % groups == 0
         Bg = B // groups
         stats = torch.empty(groups, 4, C, dtype=torch.float32, device=dev)  # per group: mean, invstd, scale, shift
-        nws = call("hpvg_bn_ws_bytes", C)
+        nws = call("hpvg_bn_ws_bytes", C * groups)
         ws = workspace(nws, dev)
         h = torch.empty_like(r)
-        for g in range(groups):
-            st = stats[g]
-            call("hpvg_bn_train_fwd_f32", ptr(r[g * Bg:(g + 1) * Bg]), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                 float(momentum), float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(h[g * Bg:(g + 1) * Bg]),
-                 1 if lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel()), Bg, C, ctypes.c_long(S), stream())
+        st = stats[0]
+        call("hpvg_bn_train_fwd_f32", ptr(r), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             float(momentum), float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(h),
+             1 if lrelu else 0, groups, ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
         ctx.save_for_backward(r, stats, gamma, beta)
         ctx.lrelu, ctx.groups = lrelu, groups
         return h
@@ -401,14 +400,12 @@ class BNAct(Function):
         sg, sb = grad_slot(gamma), grad_slot(beta)
         direct = sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
         dgb = (sg, sb) if direct else torch.empty(2, C, dtype=torch.float32, device=dev)
-        nws = call("hpvg_bn_ws_bytes", C)
+        nws = call("hpvg_bn_ws_bytes", C * groups)
         ws = workspace(nws, dev)
-        for g in range(groups):
-            st = stats[g]
-            sl = slice(g * Bg, (g + 1) * Bg)
-            call("hpvg_bn_act_bwd_f32", ptr(dh[sl]), ptr(r[sl]), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
-                 1 if ctx.lrelu else 0, ptr(dr[sl]), ptr(dgb[0]), ptr(dgb[1]), 1 if (direct or g > 0) else 0, ptr(ws),
-                 ctypes.c_size_t(ws.numel()), Bg, C, ctypes.c_long(S), stream())
+        st = stats[0]
+        call("hpvg_bn_act_bwd_f32", ptr(dh), ptr(r), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
+             1 if ctx.lrelu else 0, groups, ptr(dr), ptr(dgb[0]), ptr(dgb[1]), 1 if direct else 0, ptr(ws),
+             ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
         if direct:
             return dr, None, None, None, None, None, None, None, None
         return dr, dgb[0], dgb[1], None, None, None, None, None, None

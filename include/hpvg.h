@@ -70,14 +70,17 @@ int hpvg_bn_train_stats_f32(const float* x, const float* gamma, const float* bet
 /* the two above in two launches instead of three (the apply kernel finalizes its own channel's statistics) */
 int hpvg_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, float* y, int lrelu,
-                          void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
+                          int groups, void* ws, size_t ws_bytes, int B, int C, long S, void* stream);
+/* groups > 1: the batch holds `groups` independent passes (B / groups samples each, back to back), each normalised with its
+ * own statistics; running statistics updated once per group, in order; statistics arrays laid out [groups][4][C] (pass the
+ * addresses of group 0's mean / invstd / scale / shift); workspace hpvg_bn_ws_bytes(C * groups) */
 /* y = LeakyReLU_opt(scale[c]*x + shift[c]) (BN apply + nn.LeakyReLU(0.2), networks_3d.py:21,54-56) */
 int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int lrelu, int B, int C, long S,
                         void* stream);
 /* backward of h = LeakyReLU_opt(BN_train(r)): dr, dgamma, dbeta (native_batch_norm_backward + leaky_relu_backward);
  * accumulate != 0: dgamma / dbeta += */
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
-                        const float* shift, int lrelu, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
+                        const float* shift, int lrelu, int groups, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
                         size_t ws_bytes, int B, int C, long S, void* stream);
 /* BatchNorm with the batch split over ranks (one process per GPU): the rank-local per-channel sums are double pairs the
  * caller all-reduces (RCCL) between the two halves; statistics, running buffers and dr then follow from the global sums.
