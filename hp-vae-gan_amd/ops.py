@@ -363,8 +363,8 @@ class BNAct(Function):
 
     groups > 1: the batch holds `groups` independent passes of the network one after the other (the merged rec + rand
     generator pass, GeneratorHPVAEGAN.forward_pair); every group is normalised with ITS OWN batch statistics and the
-    running statistics are updated once per group, in order - exactly what the separate passes would do.  The groups are
-    contiguous slices of r, so the same kernels run on offset pointers."""
+    running statistics are updated once per group, in order - exactly what the separate passes would do (the kernels take
+    the group count: one launch pair for all groups)."""
 
     @staticmethod
     def forward(ctx, r, gamma, beta, running_mean, running_var, momentum, eps, lrelu, groups=1):
@@ -373,7 +373,6 @@ class BNAct(Function):
         S = T * H * W
         dev = r.device
         assert B % groups == 0
-        Bg = B // groups
         stats = torch.empty(groups, 4, C, dtype=torch.float32, device=dev)  # per group: mean, invstd, scale, shift
         nws = call("hpvg_bn_ws_bytes", C * groups)
         ws = workspace(nws, dev)
@@ -395,7 +394,6 @@ class BNAct(Function):
         S = T * H * W
         dev = r.device
         groups = ctx.groups
-        Bg = B // groups
         dr = torch.empty_like(r)
         sg, sb = grad_slot(gamma), grad_slot(beta)
         direct = sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
