@@ -859,9 +859,9 @@ inline int ew_blocks(long n) {
   if (nb > 4096) nb = 4096;
   return (int)nb;
 }
-// BatchNorm apply kernels fold the finalize in below this many elements (one round of workgroups); above, the extra
+// BatchNorm apply kernels fold the finalize in below this many elements (a few rounds of 4096-element workgroups); above, the extra
 // launch is cheaper than the per-workgroup prologue (A/B on stages 3-7: backward +0.4 %, forward neutral below the bound; fused everywhere: -1 % at stages >= 6)
-constexpr long HPVG_BN_FUSE_MAX = 1L << 23;
+constexpr long HPVG_BN_FUSE_MAX = 1L << 25;
 inline int bn_nsplit(int B, int C, long S) {
   // enough blocks to fill the chip (>= ~1024) but at least ~2048 elements per block
   long want = (1024 + C - 1) / C;
