@@ -561,7 +561,8 @@ WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
     if (cap < 1) cap = 1;
     best.S = (int)(ntiles < cap ? ntiles : cap);
     best.S0 = best.S;
-    if (KT == 3 && T >= 2 && best.S >= 2) {
+    static const bool balance = [] { const char* e = getenv("HPVG_WGRAD_BALANCE"); return !e || atoi(e) != 0; }();
+    if (balance && KT == 3 && T >= 2 && best.S >= 2) {
       // split the 3*S workgroups of a channel-block pair so that tiles-with-work per workgroup are equal:
       // centre tap: ntiles / S1, outer taps: ntiles * (T-1)/T / S0
       const long Stot = 3L * best.S;
