@@ -547,32 +547,62 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
     if (yn) yn[i] = acc + amp * noise[i];
   }
 }
-// dx (pre-zeroed) += scatter of dy
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long BC, int Ti,
-                                                            int Hi, int Wi, int To, int Ho, int Wo, float st, float sh, float sw) {
-  const long n = BC * To * Ho * Wo;
+// Backward of the resize as a GATHER: one thread per INPUT voxel sums, in a fixed order, the contributions of the output
+// voxels whose interpolation touches it (no float atomics, no pre-zeroed buffer: bitwise reproducible).  Per axis the
+// candidate outputs of input index i are those with src = scale*o in (i-1, i+1); the exact membership test re-evaluates
+// lin_coef(o) - the forward's own fp32 expression - so the weights are the forward's weights bit for bit.
+// dy2 (nullable): a second gradient of the same shape (the `up` and `up + amp*noise` outputs of one resize both carry
+// gradients into it), added on load.
+__device__ __forceinline__ void gather_range(int i, int out, float scale, int& lo, int& hi) {
+  if (!(scale > 0.f)) { lo = 0; hi = out - 1; return; }   // out == 1 (or in == 1): every output reads input 0 (and 1 with weight 0)
+  const float inv = 1.f / scale;
+  lo = (int)floorf((float)(i - 1) * inv) - 1;
+  hi = (int)ceilf((float)(i + 1) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float gather_weight(int o, int i, int in, float scale) {
+  const Lin l = lin_coef(o, in, scale);
+  float w = 0.f;
+  if (l.i0 == i) w += l.w0;
+  if (l.i1 == i) w += l.w1;
+  return w;
+}
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                            float* __restrict__ dx, long BC, int Ti, int Hi, int Wi, int To, int Ho,
+                                                            int Wo, float st, float sh, float sw) {
+  const long n = BC * Ti * Hi * Wi;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     long r = i;
-    const int wo = r % Wo; r /= Wo;
-    const int ho = r % Ho; r /= Ho;
-    const int to = r % To; r /= To;
-    float* xp = dx + r * ((long)Ti * Hi * Wi);
-    const Lin lt = lin_coef(to, Ti, st), lh = lin_coef(ho, Hi, sh), lw = lin_coef(wo, Wi, sw);
-    const float g = dy[i];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int ti = a ? lt.i1 : lt.i0;
-      const float wt = a ? lt.w1 : lt.w0;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int hi = b ? lh.i1 : lh.i0;
-        const float wh = b ? lh.w1 : lh.w0;
-        float* row = xp + ((long)ti * Hi + hi) * Wi;
-        const float w = g * wt * wh;
-        if (w * lw.w0 != 0.f) atomicAdd(row + lw.i0, w * lw.w0);
-        if (w * lw.w1 != 0.f) atomicAdd(row + lw.i1, w * lw.w1);
+    const int wi = r % Wi; r /= Wi;
+    const int hi = r % Hi; r /= Hi;
+    const int ti = r % Ti; r /= Ti;
+    const float* gp = dy + r * ((long)To * Ho * Wo);
+    const float* gp2 = dy2 ? dy2 + r * ((long)To * Ho * Wo) : nullptr;
+    int t0, t1, h0, h1, w0, w1;
+    gather_range(ti, To, st, t0, t1);
+    gather_range(hi, Ho, sh, h0, h1);
+    gather_range(wi, Wo, sw, w0, w1);
+    float acc = 0.f;
+    for (int to = t0; to <= t1; ++to) {
+      const float wt = gather_weight(to, ti, Ti, st);
+      if (wt == 0.f) continue;
+      for (int ho = h0; ho <= h1; ++ho) {
+        const float wh = gather_weight(ho, hi, Hi, sh);
+        if (wh == 0.f) continue;
+        const long row = ((long)to * Ho + ho) * Wo;
+        float racc = 0.f;
+        for (int wo = w0; wo <= w1; ++wo) {
+          const float ww = gather_weight(wo, wi, Wi, sw);
+          if (ww == 0.f) continue;
+          float g = gp[row + wo];
+          if (gp2) g += gp2[row + wo];
+          racc += ww * g;
+        }
+        acc += wt * wh * racc;
       }
     }
+    dx[i] = acc;
   }
 }
 
@@ -1177,18 +1207,15 @@ int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, fl
                      Hi, Wi, To, Ho, Wo, ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   return hpvg_launch_status();
 }
-int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
-                                    void* stream) {
-  if (!dy || !dx || BC < 1) return HPVG_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  // a kernel, not hipMemsetAsync: inside a captured hipGraph the memset NODE is not reliably ordered against the kernel
-  // nodes around it on this runtime (ROCm 7.2) - replays after a device synchronise scattered into a buffer that was
-  // zeroed too late or not at all (found with tools/soak.py: the clip norm went to inf in graph mode only)
+int hpvg_upsample_linear_ac_bwd_f32(const float* dy, const float* dy2, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho,
+                                    int Wo, void* stream) {
+  if (!dy || !dx || BC < 1 || Ti < 1 || Hi < 1 || Wi < 1 || To < 1 || Ho < 1 || Wo < 1) return HPVG_ERR_ARG;
+  // a gather over the input voxels (upsample_bwd_kernel): every dx element is written exactly once, so there is no zero
+  // fill (an earlier scatter version needed one, and a hipMemsetAsync NODE inside a captured hipGraph is not reliably
+  // ordered against the kernel nodes around it on this runtime, ROCm 7.2: DESIGN.md section 4) and no float atomics
   const long nin = BC * Ti * Hi * Wi;
-  hipLaunchKernelGGL(zero_kernel, dim3(ew_blocks(nin)), dim3(256), 0, s, dx, nin);
-  const long n = BC * To * Ho * Wo;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, BC, Ti, Hi, Wi, To, Ho, Wo,
-                     ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_blocks(nin)), dim3(256), 0, (hipStream_t)stream, dy, dy2, dx, BC, Ti, Hi, Wi, To,
+                     Ho, Wo, ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   return hpvg_launch_status();
 }
 

@@ -67,7 +67,7 @@ _SIGS = {
     "hpvg_gp_bwd_f32": [P, P, P, F, I, I, L, P],
     "hpvg_upsample_linear_ac_f32": [P, P, P, F, P, L, I, I, I, I, I, I, P],
     "hpvg_frames_resize_norm_u8_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P],
-    "hpvg_upsample_linear_ac_bwd_f32": [P, P, L, I, I, I, I, I, I, P],
+    "hpvg_upsample_linear_ac_bwd_f32": [P, P, P, L, I, I, I, I, I, I, P],
     "hpvg_sn_power_iter_f32": [P, P, P, P, P, P, I, I, I, F, P, Z, P],
     "hpvg_div_scalar_f32": [P, P, P, L, P],
     "hpvg_sn_power_iter_batch_f32": [I, P, P, P, P, P, P, P, P, I, F, P, Z, P],

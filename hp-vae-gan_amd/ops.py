@@ -706,14 +706,13 @@ class UpsampleAC(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, dyn=None):
-        if dyn is not None and dy is not None:
-            g = dy + dyn
-        else:
-            g = dy if dy is not None else dyn
+        # both outputs (`up` and `up + amp*noise`) may carry a gradient: the kernel adds the two on load
+        g, g2 = (dy, dyn) if dy is not None else (dyn, None)
         g = _c(g)
+        g2 = _c(g2) if g2 is not None else None
         BC, Ti, Hi, Wi, To, Ho, Wo = ctx.dims
         dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=g.device)
-        call("hpvg_upsample_linear_ac_bwd_f32", ptr(g), ptr(dx), ctypes.c_long(BC), Ti, Hi, Wi, To, Ho, Wo, stream())
+        call("hpvg_upsample_linear_ac_bwd_f32", ptr(g), ptr(g2), ptr(dx), ctypes.c_long(BC), Ti, Hi, Wi, To, Ho, Wo, stream())
         return dx, None, None, None
 
 

@@ -128,8 +128,10 @@ int hpvg_gp_bwd_f32(const float* gout, const float* g, float* dg, float lambda, 
  * optional fused noise injection yn = y + amp*noise (networks_3d.py:399-400).  BC = batch*channels. */
 int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, float amp, float* yn, long BC, int Ti, int Hi,
                                 int Wi, int To, int Ho, int Wo, void* stream);
-int hpvg_upsample_linear_ac_bwd_f32(const float* dy, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
-                                    void* stream);
+/* backward: dx = resize^T(dy + dy2); dy2 (nullable) is the gradient of the noisy output yn.  A gather over the input
+ * voxels in a fixed order: no float atomics, bitwise reproducible, dx need not be zeroed. */
+int hpvg_upsample_linear_ac_bwd_f32(const float* dy, const float* dy2, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho,
+                                    int Wo, void* stream);
 
 /* ---- data front-end (the step before the path): frames [N][H][W][3] uint8 RGB -> the stage's clip tensor
  * [3][count][h][w] fp32: cv2.resize(INTER_LINEAR) geometry per frame (datasets/generate_frames.py:44-46), temporal window

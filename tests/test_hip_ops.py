@@ -226,7 +226,8 @@ def test_spectral_norm_weight(ops, Co, Ci, nd):
 
 @pytest.mark.parametrize("in_shape,size", [((2, 3, 4, 18, 33), (4, 23, 41)), ((1, 3, 5, 57, 102), (7, 72, 129)),
                                            ((2, 3, 7, 20, 31), (13, 29, 40)), ((2, 3, 24, 33), (30, 41)), ((1, 2, 1, 5, 5), (1, 9, 3)),
-                                           ((1, 1, 3, 4, 5), (1, 1, 1))])
+                                           ((1, 1, 3, 4, 5), (1, 1, 1)), ((2, 3, 9, 40, 70), (4, 21, 33)),
+                                           ((1, 2, 2, 3, 4), (7, 19, 33))])
 def test_upsample(ops, in_shape, size):
     x = _rand(*in_shape, seed=40).requires_grad_(True)
     y = O.resize_linear_ac(x, size)
@@ -242,9 +243,12 @@ def test_upsample(ops, in_shape, size):
     assert_close(yd1, y, RTOL, "up.y(noisy call)")
     assert_close(ydn, y + 0.37 * noise, RTOL, "up.yn")
     g2 = _rand(*y.shape, seed=43)
-    (dxd2,) = torch.autograd.grad([yd1, ydn], xd, [gy.to(DEV), g2.to(DEV)])
+    (dxd2,) = torch.autograd.grad([yd1, ydn], xd, [gy.to(DEV), g2.to(DEV)], retain_graph=True)
     (dx2,) = torch.autograd.grad(y, x, gy + g2)
     assert_close(dxd2, dx2, RTOL, "up.dx(two outputs)")
+    # the backward is a gather in a fixed order (no float atomics): bitwise reproducible
+    (again,) = torch.autograd.grad([yd1, ydn], xd, [gy.to(DEV), g2.to(DEV)])
+    assert torch.equal(again, dxd2)
 
 
 def test_pointwise_and_losses(ops):
