@@ -427,9 +427,15 @@ class GeneratorSG(nn.Module):
         p = self.pad
         return torch.nn.functional.pad(x, (p, p, p, p, p, p))
 
-    def forward(self, noise_init, noise_amp, mode='rand'):
-        x_prev_out = self.body[0](self._zero_pad(noise_init))
-        for idx, block in enumerate(self.body[1:], 1):
+    def forward(self, noise_init, noise_amp, mode='rand', start=0, stop=None):
+        """start / stop (not in the reference; defaults = every stage): run body[start:stop] only.  For start > 0
+        `noise_init` is the previous stage's raw output (before the tanh); the raw output is returned unless the last
+        stage is included.  The level pipeline (pipeline.BaselinePipelineTrainer) keeps the other stages on other GPUs."""
+        nb = len(self.body)
+        stop = nb if stop is None else stop
+        x_prev_out = self.body[0](self._zero_pad(noise_init)) if start == 0 else noise_init
+        for idx in range(max(start, 1), stop):
+            block = self.body[idx]
             x_prev_out = ops.TanhRes.apply(x_prev_out, None)
             size = hp_utils.images.level_shape_3d(idx, self.opt)
             up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
@@ -442,7 +448,7 @@ class GeneratorSG(nn.Module):
             else:
                 x_prev = block(self._zero_pad(up))
             x_prev_out = ops.Add.apply(x_prev, up)
-        return ops.TanhRes.apply(x_prev_out, None)
+        return ops.TanhRes.apply(x_prev_out, None) if stop == nb else x_prev_out
 
 
 class GeneratorCSG(nn.Module):

@@ -191,10 +191,15 @@ def _bn_block_valid(x, P, prefix):
                                        P[prefix + '.norm.running_var']))
 
 
-def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None):
-    """GeneratorSG.forward (networks_3d.py:298-322): valid 7-conv stacks on volumes padded by num_layer+2."""
+def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None, start=0, stop=None):
+    """GeneratorSG.forward (networks_3d.py:298-322): valid 7-conv stacks on volumes padded by num_layer+2.
+    start / stop (not in the reference; defaults = the whole generator): run stages [start, stop) only - `noise_init` is
+    then the previous stage's raw output (before the tanh) for start > 0, and the raw output is returned unless the last
+    stage is included (the level pipeline keeps the other stages on other ranks)."""
     pad = opt.num_layer + 2
     p6 = (pad,) * 6
+    nb = num_body(P)
+    stop = nb if stop is None else stop
 
     def stack(x, k):
         h = _bn_block_valid(x, P, 'body.%d.head' % k)
@@ -202,8 +207,8 @@ def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None
             h = _bn_block_valid(h, P, 'body.%d.block%d' % (k, i))
         return conv_valid(h, P['body.%d.tail.weight' % k], P['body.%d.tail.bias' % k])
 
-    x = stack(F.pad(noise_init, p6), 0)
-    for idx in range(1, num_body(P)):
+    x = stack(F.pad(noise_init, p6), 0) if start == 0 else noise_init
+    for idx in range(max(start, 1), stop):
         x = torch.tanh(x)
         size = level_shape(idx, opt, 3)
         up = resize_linear_ac(x, size)
@@ -214,7 +219,7 @@ def generator_sg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None
         else:
             xp = stack(F.pad(up, p6), idx)
         x = xp + up
-    return torch.tanh(x)
+    return torch.tanh(x) if stop == nb else x
 
 
 def generator_csg_forward(P, opt, noise_init, noise_amp, mode='rand', noises=None):
@@ -492,7 +497,8 @@ def train_step(PG, PD, opt, dims, scale_idx, real, real_zero, noise_init, noises
         errG = -discriminator_forward(fake, PD, opt).mean() * opt.disc_loss_weight
         total = opt.rec_weight * rec_loss + errG
         out.update(errD_real=errD_real.detach(), errD_fake=errD_fake.detach(), gradient_penalty=gp.detach(),
-                   rec_loss=rec_loss.detach(), errG=errG.detach())
+                   rec_loss=rec_loss.detach(), errG=errG.detach(), fake=fake.detach())
+    out.update(generated=generated.detach(), generated_vae=generated_vae.detach(), mu=mu.detach(), logvar=logvar.detach())
     keys = list(gparams.keys())
     grads = torch.autograd.grad(total, [gparams[k] for k in keys], allow_unused=True)
     out['total_loss'] = total.detach()

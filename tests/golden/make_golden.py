@@ -113,8 +113,42 @@ class KinkMargin:
             h.remove()
 
 
+SEED_OVERRIDE = [None]   # main(): re-run a job on exactly the seed its first run settled on
+# main(): relative perturbation applied to the input clip of a re-run (2^-20: the size of the difference between two fp32
+# implementations after a few dozen layers).  The spread between the plain and the perturbed run is how much the reference
+# itself moves when its rounding is disturbed - after an optimizer step that includes Adam's sign flips of ~0 gradients.
+INPUT_EPS = [0.0]
+
+
+def iter_spread(a, b):
+    """max |a - b| per recorded quantity of one iteration (tensors; dicts of tensors -> dict)."""
+    out = {}
+    for k, va in a.items():
+        vb = b.get(k)
+        if torch.is_tensor(va) and va.dtype.is_floating_point:
+            out[k] = float((va.double() - vb.double()).abs().max()) if va.numel() else 0.0
+        elif isinstance(va, dict):
+            out[k] = {n: (float((t.double() - vb[n].double()).abs().max()) if (torch.is_tensor(t) and t.dtype.is_floating_point and t.numel()) else 0.0)
+                      for n, t in va.items() if t is not None}
+        elif isinstance(va, list) and va and isinstance(va[0], (int, float)):
+            out[k] = max(abs(x - y) for x, y in zip(va, vb))
+    return out
+
+
+def merge_spread(a, b):
+    if isinstance(a, dict):
+        return {k: merge_spread(a[k], b[k]) for k in a}
+    if a is None or b is None:
+        return a if b is None else b
+    if isinstance(a, list):
+        return [max(x, y) for x, y in zip(a, b)]
+    return max(a, b)
+
+
 def with_kink_margin(make, seed, min_margin, tries=200):
     """Run make(seed') for seed' = seed, seed+1000, ... until the LeakyReLU kink margin of the draw is >= min_margin."""
+    if SEED_OVERRIDE[0] is not None:
+        return make(SEED_OVERRIDE[0])
     best = None
     for k in range(tries):
         fx = make(seed + 1000 * k)
@@ -194,6 +228,9 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
 
     real = torch.rand(opt.batch_size, 3, *shape(scale_idx), generator=gen) * 2 - 1
     real_zero = torch.rand(opt.batch_size, 3, *shape(0), generator=gen) * 2 - 1 if scale_idx > 0 else real
+    if INPUT_EPS[0]:
+        real_zero = real_zero * (1 + INPUT_EPS[0]) if scale_idx > 0 else real * (1 + INPUT_EPS[0])
+        real = real * (1 + INPUT_EPS[0]) if scale_idx > 0 else real_zero
     z_size = [opt.batch_size, opt.latent_dim, *shape(0)]
     # earlier stages' amplitudes (any plausible values; the last one is calibrated at iteration 0)
     noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx)]
@@ -256,6 +293,169 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
     return fx
 
 
+class DetNoise:
+    """Replace every Tensor.normal_() by tests/detfill.det_normal(shape, 'n<k>') (k = call index) and torch.rand by a
+    constant: a step whose inputs are all closed-form (nothing but output summaries needs storing)."""
+    ALPHA = 0.37
+
+    def __init__(self):
+        self.shapes = []
+
+    def __enter__(self):
+        import detfill
+        self._normal = torch.Tensor.normal_
+        self._rand = torch.rand
+        rec = self
+
+        def normal_(t, *a, **k):
+            with torch.no_grad():
+                t.copy_(detfill.det_normal(tuple(t.shape), 'n%d' % len(rec.shapes)))
+            rec.shapes.append(list(t.shape))
+            return t
+
+        def rand(*a, **k):
+            return torch.full(a if not (len(a) == 1 and isinstance(a[0], (tuple, list))) else tuple(a[0]), DetNoise.ALPHA)
+
+        torch.Tensor.normal_ = normal_
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._normal
+        torch.rand = self._rand
+
+
+def run_wide_step(images, nets, losses, mutils, opt, dims, scale_idx, threads):
+    """ONE iteration of train() (train_video.py:111-202) at the BASELINE widths (nfc 64, latent 128, the 256-wide
+    pyramid) on the reference modules.  Weights, inputs and noise come from tests/detfill.py (closed form), so the fixture
+    holds output SUMMARIES only (norm, abs-max, strided sample per tensor)."""
+    import detfill
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    images.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    netG = nets.GeneratorHPVAEGAN(opt)
+    for _ in range(scale_idx):
+        netG.init_next_stage()
+    netG.load_state_dict(detfill.fill_state(netG.state_dict(), 'G'))
+    gan = opt.vae_levels < scale_idx + 1
+    D = None
+    if gan:
+        D = (nets.WDiscriminator3D if dims == 3 else nets.WDiscriminator2D)(opt)
+        D.load_state_dict(detfill.fill_state(D.state_dict(), 'D'))
+        optimizerD = optim.Adam(D.parameters(), lr=opt.lr_d, betas=(opt.beta1, 0.999))
+    optimizerG = optim.Adam(g_param_list(netG, opt, scale_idx), lr=opt.lr_g, betas=(opt.beta1, 0.999))
+    G0, D0 = sd_clone(netG), (sd_clone(D) if gan else None)
+
+    def shape(i):
+        w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+        if dims == 3:
+            _, td, _ = images.get_fps_td_by_index(i, opt)
+            return [td, int(w * opt.ar), w]
+        return [int(w * opt.ar), w]
+
+    real = detfill.det_uniform([opt.batch_size, 3, *shape(scale_idx)], 'real')
+    real_zero = detfill.det_uniform([opt.batch_size, 3, *shape(0)], 'real_zero') if scale_idx > 0 else real
+    if INPUT_EPS[0]:
+        real_zero = real_zero * (1 + INPUT_EPS[0]) if scale_idx > 0 else real * (1 + INPUT_EPS[0])
+        real = real * (1 + INPUT_EPS[0]) if scale_idx > 0 else real_zero
+    z_size = [opt.batch_size, opt.latent_dim, *shape(0)]
+    noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx)]
+    rec_loss_fn = torch.nn.MSELoss()
+    out = {}
+    with DetNoise() as rec:
+        noise_init = images.generate_noise(size=z_size, device='cpu')
+        with torch.no_grad():
+            if scale_idx == 0:
+                noise_amps.append(1)
+            else:
+                noise_amps.append(0)
+                z_rec, _, _ = netG(real_zero, noise_amps, mode="rec")
+                rmse = torch.sqrt(F.mse_loss(real, z_rec))
+                noise_amps[-1] = opt.noise_amp_init * rmse.item() / opt.batch_size
+        generated, generated_vae, (mu, logvar) = netG(real_zero, noise_amps, mode="rec")
+        if not gan:
+            rec_vae_loss = rec_loss_fn(generated, real) + rec_loss_fn(generated_vae, real_zero)
+            kl_loss = losses.kl_criterion(mu, logvar)
+            total_loss = opt.rec_weight * rec_vae_loss + opt.kl_weight * kl_loss
+            out.update(rec_vae_loss=float(rec_vae_loss), kl_loss=float(kl_loss))
+        else:
+            D.zero_grad()
+            errD_real = -D(real).mean()
+            fake, _ = netG(noise_init, noise_amps, noise_init=noise_init, mode="rand")
+            errD_fake = D(fake.detach()).mean()
+            gp = mutils.calc_gradient_penalty(D, real, fake, opt.lambda_grad, 'cpu')
+            (errD_real + errD_fake + gp).backward()
+            out['gradsD'] = {n: detfill.summarize(p.grad, 256) for n, p in D.named_parameters()}
+            optimizerD.step()
+            rec_loss = rec_loss_fn(generated, real)
+            errG = -D(fake).mean() * opt.disc_loss_weight
+            total_loss = opt.rec_weight * rec_loss + errG
+            out.update(errD_real=float(errD_real), errD_fake=float(errD_fake), gradient_penalty=float(gp), rec_loss=float(rec_loss),
+                       errG=float(errG), fake=detfill.summarize(fake, 4096))
+        netG.zero_grad()
+        total_loss.backward()
+        out['gradsG'] = {n: (detfill.summarize(p.grad, 256) if p.grad is not None else None) for n, p in netG.named_parameters()}
+        total_norm = torch.nn.utils.clip_grad_norm_(netG.parameters(), opt.grad_clip)
+        optimizerG.step()
+    out.update(total_loss=float(total_loss), total_norm=float(total_norm), noise_amps=list(noise_amps), noise_shapes=rec.shapes,
+               alpha=DetNoise.ALPHA, generated=detfill.summarize(generated, 4096), generated_vae=detfill.summarize(generated_vae, 4096),
+               mu=detfill.summarize(mu, 4096), logvar=detfill.summarize(logvar, 4096))
+    G1 = sd_clone(netG)
+    out['G_delta'] = {k: detfill.summarize(G1[k].float() - G0[k].float(), 256) for k, _ in netG.named_parameters()}
+    out['G_buffers'] = {k: v.clone() for k, v in G1.items() if k.endswith(('running_mean', 'running_var', 'weight_u', 'weight_v', 'num_batches_tracked'))}
+    if gan:
+        D1 = sd_clone(D)
+        out['D_delta'] = {k: detfill.summarize(D1[k].float() - D0[k].float(), 256) for k, _ in D.named_parameters()}
+        out['D_buffers'] = {k: v.clone() for k, v in D1.items() if k.endswith(('weight_u', 'weight_v'))}
+    return out
+
+
+def _spread(a, b):
+    """Per-entry difference of two runs of the same step (1 thread vs 8 threads of the reference's own CPU kernels): the
+    yardstick for how far two correct fp32 implementations drift apart on each quantity."""
+    if isinstance(a, dict) and 'sample' in a:
+        return {'norm': abs(a['norm'] - b['norm']), 'sample': float((a['sample'].double() - b['sample'].double()).abs().max()),
+                'frac_lr10': None}
+    if isinstance(a, dict):
+        return {k: _spread(a[k], b[k]) for k in a if a[k] is not None}
+    if isinstance(a, float):
+        return abs(a - b)
+    if torch.is_tensor(a) and a.dtype.is_floating_point:
+        return float((a.double() - b.double()).abs().max())
+    if isinstance(a, list) and a and isinstance(a[0], float):
+        return [abs(x - y) for x, y in zip(a, b)]
+    return None
+
+
+def wide_fixture(images, nets, losses, mutils, dims, scale_idx):
+    def opt():
+        return make_opt(nfc=64, latent_dim=128, vae_levels=3, min_size=32, max_size=256, img_size=256, ar=144.0 / 256.0)
+    one = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
+    with torch.backends.mkldnn.flags(enabled=False):   # 8 threads AND ATen's native conv kernels instead of oneDNN
+        many = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=8)
+    INPUT_EPS[0] = 2.0 ** -20
+    try:
+        pert = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
+    finally:
+        INPUT_EPS[0] = 0.0
+    torch.set_num_threads(1)
+    o = opt()
+    images.adjust_scales2image(o.img_size, o)
+    lr = o.lr_g
+    spread = merge_spread(_spread(one, many), _spread(one, pert))
+    for name in ('G_delta', 'D_delta'):   # fraction of sampled weights whose update differs by more than lr/10 between the runs
+        if name in one:
+            for k in one[name]:
+                fr = 0.0
+                for other in (many, pert):
+                    d = (one[name][k]['sample'].double() - other[name][k]['sample'].double()).abs()
+                    fr = max(fr, float((d > lr / 10).double().mean()))
+                spread[name][k]['frac_lr10'] = fr
+    return {'opt': {k: v for k, v in vars(o).items() if isinstance(v, (int, float, bool, list, str))}, 'dims': dims,
+            'scale_idx': scale_idx, 'expected': one, 'spread': spread}
+
+
 def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, generator='GeneratorSG', discriminator='WDiscriminator3D'):
     """train_video_baselines.py:93-173 driven around the reference's GeneratorSG / GeneratorCSG + WDiscriminator3D."""
     torch.manual_seed(seed)
@@ -287,6 +487,8 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
         return [td, int(w * opt.ar), w]
 
     real = torch.rand(opt.batch_size, 3, *shape(scale_idx), generator=gen) * 2 - 1
+    if INPUT_EPS[0]:
+        real = real * (1 + INPUT_EPS[0])
     Z_init = torch.randn(opt.batch_size, 3, *shape(0), generator=gen)
     noise_amps = [1] + [0.05 + 0.01 * k for k in range(1, scale_idx)]
     rec_loss_fn = torch.nn.MSELoss()
@@ -498,13 +700,43 @@ def main():
         'step3d_gan_s3_td2.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2, train_depth=2), 3, 3, 1, seed=107),
         'step3d_gan_s2_all.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=1, train_all=True, train_depth=8), 3, 2, 1, seed=108),
     }
+    sys.path.insert(0, os.path.dirname(OUT))   # tests/detfill.py
+    small8 = dict(nfc=4, latent_dim=4, vae_levels=3, img_size=48, min_size=7, max_size=48, sampling_rates=[2, 2, 1, 1], fps_lcm=2)
+    jobs.update({
+        # whole steps at the BASELINE widths (nfc 64, latent 128, 256-wide pyramid): closed-form inputs, output summaries
+        'wide3d_vae_s0.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 0),
+        'wide3d_gan_s3.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 3),
+        # 8-level pyramids (BASELINE configs[3] / configs[4]: one level per GPU on 8 GPUs), tiny widths: the world-8 gloo tests
+        'step3d_gan_s7.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(**small8), 3, 7, 1, seed=111),
+        'baseline3d_sg_s7.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=1, **small8),
+                                                          7, 1, seed=112),
+    })
     want = sys.argv[1:] or ['tables.json'] + list(jobs)
     if 'tables.json' in want:
         with open(os.path.join(OUT, 'tables.json'), 'w') as f:
             json.dump(table_fixtures(images), f, indent=1)
     for name in want:
         if name in jobs:
-            torch.save(jobs[name](), os.path.join(OUT, name))
+            fx = jobs[name]()
+            if isinstance(fx, dict) and 'iters' in fx and 'seed' in fx:
+                # the same draw through the reference once more, on 8 threads and with oneDNN switched off (ATen's native
+                # convolution kernels): per-quantity spread between two correct fp32 evaluations of the reference
+                # (summation order; after an optimizer step also Adam's sign flips) - the tests' tolerance yardstick
+                torch.set_num_threads(8)
+                SEED_OVERRIDE[0] = fx['seed']
+                try:
+                    with torch.backends.mkldnn.flags(enabled=False):   # ATen's native conv kernels: another summation order
+                        fx8 = jobs[name]()
+                finally:
+                    SEED_OVERRIDE[0] = None
+                    torch.set_num_threads(1)
+                SEED_OVERRIDE[0], INPUT_EPS[0] = fx['seed'], 2.0 ** -20
+                try:
+                    fxp = jobs[name]()
+                finally:
+                    SEED_OVERRIDE[0], INPUT_EPS[0] = None, 0.0
+                fx['spread'] = [merge_spread(iter_spread(a, b), iter_spread(a, c)) for a, b, c in zip(fx['iters'], fx8['iters'], fxp['iters'])]
+            torch.save(fx, os.path.join(OUT, name))
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -130,3 +130,167 @@ def flat_to_named(flat, arena, module):
         o, k = arena.range[id(p)]
         out[n] = flat[o:o + k].view(p.shape)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ wide (BASELINE-width) steps
+def wide_inputs(fx, keysG, keysD):
+    """Everything a wide fixture's step consumes, regenerated from tests/detfill.py: (opt, G state, D state, real, real_zero,
+    noise_init, [noise tensors in the reference's draw order after noise_init], alpha).  keysG / keysD: state_dicts (any
+    values) with the reference's key layout and shapes."""
+    import detfill
+    from oracle import hpvg_oracle as O
+    opt = opt_from(fx["opt"])
+    O.adjust_scales2image(opt.img_size, opt)
+    opt.stop_scale_time = opt.stop_scale
+    dims, s = fx["dims"], fx["scale_idx"]
+    G = detfill.fill_state(keysG, "G")
+    D = detfill.fill_state(keysD, "D") if keysD is not None else None
+    real = detfill.det_uniform([opt.batch_size, 3, *O.level_shape(s, opt, dims)], "real")
+    real_zero = detfill.det_uniform([opt.batch_size, 3, *O.level_shape(0, opt, dims)], "real_zero") if s > 0 else real
+    shapes = fx["expected"]["noise_shapes"]
+    draws = [detfill.det_normal(tuple(sh), "n%d" % i) for i, sh in enumerate(shapes)]
+    alpha = torch.full((1, 1), float(fx["expected"]["alpha"]))
+    return opt, G, D, real, real_zero, draws[0], draws[1:], alpha
+
+
+def _bn_fed_bias(name, names):
+    return name.endswith(".conv.bias") and (name[:-len("conv.bias")] + "norm.weight") in names
+
+
+def wide_compare(fx, got, lr_of_G, lr_d, what):
+    """Compare a step's results with a wide fixture.  Tolerance per quantity: max(north_star 1e-3 relative, 2 x the spread
+    the reference itself shows between its oneDNN / 1-thread and native-ATen / 8-thread evaluations of the same step).
+    Parameter UPDATES (not parameters) are compared: frozen parameters must not move at all, trained ones must match the
+    reference's Adam step except on a small fraction (sign flips of ~0 gradients), bounded by the reference's own."""
+    import detfill
+    exp, spr = fx["expected"], fx["spread"]
+    for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG", "total_norm"):
+        if k in exp:
+            tol = max(RTOL * abs(exp[k]), 2 * spr[k], 1e-7)
+            assert abs(float(got[k]) - exp[k]) <= tol, "%s.%s: %r vs %r (tol %.2e)" % (what, k, float(got[k]), exp[k], tol)
+    assert [float(a) for a in got["noise_amps"]] == pytest_approx([float(a) for a in exp["noise_amps"]], 1e-4), what + ".noise_amps"
+
+    def tensor(name, t, e, s, count, atol=0.0):
+        assert list(t.shape) == e["shape"], "%s.%s: shape %s vs %s" % (what, name, list(t.shape), e["shape"])
+        m = detfill.summarize(t.detach().cpu(), count)
+        tol = max(RTOL * e["absmax"], 2 * s["sample"], atol)
+        err = float((m["sample"].double() - e["sample"].double()).abs().max()) if m["sample"].numel() else 0.0
+        assert err <= tol, "%s.%s: sample err %.3e > tol %.3e (absmax %.3e)" % (what, name, err, tol, e["absmax"])
+        ntol = max(RTOL * e["norm"], 2 * s["norm"], atol * max(1.0, float(t.numel()) ** 0.5))
+        assert abs(m["norm"] - e["norm"]) <= ntol, "%s.%s: norm %.6e vs %.6e (tol %.2e)" % (what, name, m["norm"], e["norm"], ntol)
+
+    for k in ("generated", "generated_vae", "mu", "logvar", "fake"):
+        if k in exp:
+            tensor(k, got[k], exp[k], spr[k], 4096)
+    for key, count in (("gradsG", 256), ("gradsD", 256)):
+        if key not in exp:
+            continue
+        names = set(exp[key])
+        # the per-tensor spread is a two-sample estimate; the largest RELATIVE spread over the tensors of the same family
+        # (one network's gradients in one backward pass, BatchNorm-fed conv biases aside) steadies it
+        fam = max([spr[key][n]["sample"] / e["absmax"] for n, e in exp[key].items()
+                   if e is not None and e["absmax"] > 0 and not _bn_fed_bias(n, names)] + [0.0])
+        for n, e in exp[key].items():
+            if e is None:
+                g = got[key].get(n)
+                assert g is None or float(g.abs().max()) == 0.0, "%s.%s.%s should have no gradient" % (what, key, n)
+                continue
+            atol = max(1e-7, fam * e["absmax"])
+            if _bn_fed_bias(n, names):   # exactly-zero true gradient: rounding noise, judged on the layer's weight gradient
+                atol = 1e-4 * exp[key][n[:-len("bias")] + "weight"]["absmax"]
+            tensor(key + "." + n, got[key][n], e, spr[key][n], count, atol=atol)
+    for key, lr_of in (("G_delta", lr_of_G), ("D_delta", lambda n: lr_d)):
+        if key not in exp:
+            continue
+        names = set(exp[key])
+        for n, e in exp[key].items():
+            d = got[key][n].detach().cpu().double().reshape(-1)
+            lr = lr_of(n)
+            if lr is None:   # outside every optimizer group: must not move
+                assert e["absmax"] == 0.0 and float(d.abs().max()) == 0.0, "%s.%s.%s: a frozen parameter moved" % (what, key, n)
+                continue
+            assert float(d.abs().max()) <= lr * (1 + 1e-3) + 2.4e-7, "%s.%s.%s: |update| %.3e exceeds the Adam bound lr = %.3e" % (what, key, n, float(d.abs().max()), lr)
+            if _bn_fed_bias(n, names):
+                continue         # gradient is rounding noise: size and sign of the update are arbitrary on both sides
+            if e["absmax"] > 0:  # the reference moved it: so must we (a skipped optimizer step / wrong arena range fails here)
+                assert float(d.abs().max()) >= 0.5 * e["absmax"], "%s.%s.%s: update %.3e, reference %.3e" % (what, key, n, float(d.abs().max()), e["absmax"])
+            idx = detfill.sample_idx(d.numel(), 256)
+            diff = (d[idx] - e["sample"].double()).abs()
+            frac = float((diff > lr / 10).double().mean())
+            allowed = max(0.02, 2 * (spr[key][n]["frac_lr10"] or 0.0))
+            assert frac <= allowed, "%s.%s.%s: %.1f %% of the sampled updates differ by more than lr/10 (allowed %.1f %%)" % (
+                what, key, n, 100 * frac, 100 * allowed)
+            # away from sign flips the first Adam step is -lr*g/(|g| + 1e-8) ~ -lr*sign(g): a group learning rate that is off
+            # by a few per cent (a wrong lr_scale power) shows up here
+            frac2 = float((diff > lr / 100).double().mean())
+            assert frac2 <= allowed + 0.03, "%s.%s.%s: %.1f %% of the sampled updates differ by more than lr/100" % (what, key, n, 100 * frac2)
+    for key in ("G_buffers", "D_buffers"):
+        if key not in exp:
+            continue
+        for n, v in exp[key].items():
+            if n.endswith("num_batches_tracked"):
+                assert int(got[key][n]) == int(v), "%s.%s.%s" % (what, key, n)
+            else:
+                assert_close(got[key][n].float().cpu(), v.float(), RTOL, "%s.%s.%s" % (what, key, n), atol=max(1e-6, 2 * spr[key].get(n) if isinstance(spr.get(key), dict) and spr[key].get(n) is not None else 1e-6))
+
+
+def pytest_approx(v, rel):
+    import pytest
+    return pytest.approx(v, rel=rel)
+
+
+# ------------------------------------------------------------------------------------------------ recorded (small) step fixtures
+def _amax(t):
+    return float(t.detach().double().abs().max()) if t.numel() else 0.0
+
+
+def compare_update(what, before, after_ref, after_got, lr, spread_frac=0.0, bn_fed=False, first_step=True):
+    """A parameter's UPDATE (after - before) against the reference's.  lr None: the parameter is outside every optimizer
+    group and must not move (exact).  Otherwise Adam's step: bounded by lr (first step) and equal to the reference's except
+    where a ~0 gradient flipped its sign (fraction of elements off by more than lr/10, bounded by 2 % or twice the
+    reference's own fraction between its evaluations)."""
+    d_ref = (after_ref.double() - before.double()).reshape(-1)
+    d_got = (after_got.detach().cpu().double() - before.double()).reshape(-1)
+    if lr is None:
+        assert _amax(d_ref) == 0.0 and _amax(d_got) == 0.0, "%s: a parameter outside the optimizer groups moved (%.3e)" % (what, _amax(d_got))
+        return
+    ulp = 1.2e-7 * _amax(before)   # the update is read off fp32 parameters: one rounding of the parameter itself
+    bound = (lr * (1 + 1e-3) if first_step else 3 * lr) + ulp
+    assert _amax(d_got) <= bound, "%s: |update| %.3e exceeds %.3e" % (what, _amax(d_got), bound)
+    if bn_fed:
+        return   # exactly-zero true gradient: rounding noise decides size and sign of the update on both sides
+    if _amax(d_ref) > 0:
+        assert _amax(d_got) >= 0.5 * _amax(d_ref), "%s: update %.3e, reference %.3e (skipped step / wrong range?)" % (what, _amax(d_got), _amax(d_ref))
+    diff = (d_got - d_ref).abs()
+    frac = float((diff > lr / 10).double().mean())
+    allowed = max(0.02, 2 * spread_frac)
+    assert frac <= allowed, "%s: %.2f %% of the updates differ from the reference's by more than lr/10 (allowed %.2f %%)" % (what, 100 * frac, 100 * allowed)
+    frac2 = float((diff > lr / 100).double().mean())
+    assert frac2 <= allowed + 0.03, "%s: %.2f %% of the updates differ by more than lr/100" % (what, 100 * frac2)
+
+
+def compare_step(what, rec, spread, got, rtol=RTOL):
+    """Losses, outputs, gradients and the clip norm of one recorded iteration.  `spread` (may be None for old fixtures):
+    the reference's own per-quantity spread; tolerance = max(rtol * scale, 2 * spread[, family floor])."""
+    spread = spread or {}
+    for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG", "total_norm"):
+        if k in rec and k in got:
+            assert_close(torch.as_tensor(got[k]).reshape(()), rec[k].reshape(()), rtol, "%s.%s" % (what, k), atol=2 * spread.get(k, 0.0))
+    for k in ("generated", "generated_vae", "mu", "logvar", "fake"):
+        if k in rec and k in got and rec[k] is not None:
+            assert_close(got[k], rec[k], rtol, "%s.%s" % (what, k), atol=2 * spread.get(k, 0.0))
+    for key in ("gradsG", "gradsD"):
+        if key not in rec or key not in got:
+            continue
+        names = set(n for n, g in rec[key].items() if g is not None)
+        sp = spread.get(key, {})
+        fam = max([sp.get(n, 0.0) / _amax(rec[key][n]) for n in names if _amax(rec[key][n]) > 0 and not _bn_fed_bias(n, names)] + [0.0])
+        for n, g in rec[key].items():
+            mine = got[key].get(n)
+            if g is None:
+                assert mine is None or _amax(mine) == 0.0, "%s.%s.%s should have no gradient" % (what, key, n)
+                continue
+            atol = max(1e-7, 2 * sp.get(n, 0.0), fam * _amax(g))
+            if _bn_fed_bias(n, names):
+                atol = max(bn_bias_atol(n, rec[key], 1e-7), 0.0)
+            assert_close(mine, g, rtol, "%s.%s.%s" % (what, key, n), atol=atol)

@@ -4,51 +4,65 @@ parameters, BN running stats, SN u/v and the calibrated noise amplitude."""
 import pytest
 import torch
 
-from helpers import RTOL, assert_close, bn_bias_atol, flat_to_named, load_golden, run_hip_stage
+from helpers import RTOL, assert_close, bn_bias_atol, flat_to_named, load_golden, run_hip_stage  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("fname", ["step3d_vae_s0.pt", "step3d_vae_s1.pt", "step3d_gan_s3.pt", "step2d_gan_s2.pt", "step2d_vae_s1.pt",
-                                   "step3d_gan_s3_td2.pt", "step3d_gan_s2_all.pt"])
+                                   "step3d_gan_s3_td2.pt", "step3d_gan_s2_all.pt", "step3d_gan_s7.pt"])
 def test_train_step_matches_reference(fname):
+    """Tolerances are measured, not guessed: each quantity gets max(1e-3 relative (north_star), 2 x the spread the reference
+    itself shows for it between its oneDNN, native-ATen and input-perturbed (2^-20) evaluations; fx["spread"]).  Post-step
+    parameters are judged by their UPDATE: frozen parameters must be bit-identical to the initial state, trained ones must
+    make the reference's Adam step (learning rate of their group, bounded by lr) except on the sign-flip fraction."""
+    from helpers import _bn_fed_bias, compare_step, compare_update
+    from hp_vae_gan_amd import train as hp_train
     fx = load_golden(fname)
-    gan = fx["D_init"] is not None
-    # quantities computed AFTER an optimizer step (GAN stage: errG and the G gradients go through the just-updated D;
-    # any iteration > 0) inherit Adam's +-lr sign-flip sensitivity: 3e-3 there, 1e-3 elsewhere
+    prevG = {k: v.clone() for k, v in fx["G_init"].items()}
+    prevD = {k: v.clone() for k, v in fx["D_init"].items()} if fx["D_init"] is not None else None
     for it, (rec, out, netG, netD, trainer) in enumerate(run_hip_stage(fx)):
-        post = 3e-3 if (gan or it > 0) else RTOL
+        spread = fx["spread"][it] if "spread" in fx else None
+        what = "%s[%d]" % (fname, it)
         assert trainer.opt.Noise_Amps == pytest.approx(rec["noise_amps"], rel=1e-4)
-        for k in ("total_loss", "rec_vae_loss", "kl_loss", "errD_real", "errD_fake", "gradient_penalty", "rec_loss", "errG"):
-            if k in rec:
-                tol = post if (k in ("errG", "total_loss") or it > 0) else RTOL
-                assert_close(out[k], rec[k], tol, "%s[%d].%s" % (fname, it, k))
-        for k in ("generated", "generated_vae", "mu", "logvar", "fake"):
-            if k in rec and k in out:
-                assert_close(out[k], rec[k], RTOL if it == 0 else post, "%s[%d].%s" % (fname, it, k))
-        gotG = flat_to_named(out["gradG_flat"], trainer.arenaG, netG)
-        for k, g in rec["gradsG"].items():
-            if g is None:
-                assert float(gotG[k].abs().max()) == 0.0, k
-            else:
-                assert_close(gotG[k], g, post, "%s[%d].gradG.%s" % (fname, it, k), atol=bn_bias_atol(k, rec["gradsG"], 1e-7))
-        assert_close(out["clip_info"][1], rec["total_norm"], post, "%s[%d].total_norm" % (fname, it))
+        got = dict(out)
+        got["total_norm"] = out["clip_info"][1]
+        got["gradsG"] = flat_to_named(out["gradG_flat"], trainer.arenaG, netG)
         if "gradsD" in rec:
-            gotD = flat_to_named(out["gradD_flat"], trainer.arenaD, netD)
-            for k, g in rec["gradsD"].items():
-                if g is None:
-                    assert float(gotD[k].abs().max()) == 0.0, k
-                else:
-                    assert_close(gotD[k], g, RTOL if it == 0 else post, "%s[%d].gradD.%s" % (fname, it, k), atol=1e-7)
-        # post-step state: Adam moves a weight by ~lr*sign(g) (sign flips of ~0 gradients), so allow it+1 steps of lr
-        lr = fx["opt"]["lr_g"] * (it + 1)
+            got["gradsD"] = flat_to_named(out["gradD_flat"], trainer.arenaD, netD)
+        compare_step(what, rec, spread, got)
+        # ---- post-step state, by update
+        lr_by_id = {}
+        for params, lr in hp_train.generator_param_groups(trainer.opt, netG):
+            for p in params:
+                lr_by_id[id(p)] = lr
         sdG = netG.state_dict()
+        gnames = dict(netG.named_parameters())
         for k, v in rec["G_after"].items():
-            assert_close(sdG[k].float(), v.float(), RTOL, "%s[%d].G_after.%s" % (fname, it, k), atol=2 * lr)
+            if k in gnames:
+                sf = 0.0
+                if spread is not None:
+                    lr_k = lr_by_id.get(id(gnames[k]))
+                    # the reference's own sign-flip fraction is not recorded per tensor for these fixtures; its spread on the
+                    # tensor (max |difference| between evaluations) tells whether ANY element flipped
+                    sf = 0.05 if (lr_k and spread["G_after"].get(k, 0.0) > lr_k / 10) else 0.0
+                compare_update(what + ".G." + k, prevG[k], v, sdG[k], lr_by_id.get(id(gnames[k])), sf,
+                               _bn_fed_bias(k, set(gnames)), first_step=(it == 0))
+            elif k.endswith("num_batches_tracked"):
+                assert int(sdG[k]) == int(v), what + "." + k
+            else:
+                assert_close(sdG[k].float(), v.float(), RTOL, what + ".G_after." + k, atol=max(1e-6, 2 * (spread or {}).get("G_after", {}).get(k, 0.0)))
+        prevG = {k: v.clone() for k, v in rec["G_after"].items()}
         if rec["D_after"] is not None:
             sdD = netD.state_dict()
+            dnames = dict(netD.named_parameters())
             for k, v in rec["D_after"].items():
-                assert_close(sdD[k].float(), v.float(), RTOL, "%s[%d].D_after.%s" % (fname, it, k), atol=2 * lr)
+                if k in dnames:
+                    sf = 0.05 if (spread is not None and spread["D_after"].get(k, 0.0) > fx["opt"]["lr_d"] / 10) else 0.0
+                    compare_update(what + ".D." + k, prevD[k], v, sdD[k], fx["opt"]["lr_d"], sf, False, first_step=(it == 0))
+                else:
+                    assert_close(sdD[k].float(), v.float(), RTOL, what + ".D_after." + k, atol=max(1e-6, 2 * (spread or {}).get("D_after", {}).get(k, 0.0)))
+            prevD = {k: v.clone() for k, v in rec["D_after"].items()}
 
 
 def test_sampling_path_matches_reference():
@@ -86,7 +100,8 @@ def test_smoke_entry():
 
 @pytest.mark.parametrize("fname,generator,critic", [("baseline3d_s2.pt", "GeneratorSG", "WDiscriminator3D"),
                                                     ("baseline3d_csg_s2.pt", "GeneratorCSG", "WDiscriminator3D"),
-                                                    ("baseline3d_dbl_s1.pt", "GeneratorSG", "WDiscriminatorBaselines")])
+                                                    ("baseline3d_dbl_s1.pt", "GeneratorSG", "WDiscriminatorBaselines"),
+                                                    ("baseline3d_sg_s7.pt", "GeneratorSG", "WDiscriminator3D")])
 def test_baseline_singan_step_matches_reference(fname, generator, critic):
     """BASELINE config 5 (GeneratorSG) and the baselines script's default GeneratorCSG: BaselineStageTrainer (HIP)
     against the reference-generated fixtures."""
@@ -115,24 +130,39 @@ def test_baseline_singan_step_matches_reference(fname, generator, critic):
     netG.noise_source = NoiseFeed(rec["noises"], dev)
     out = tr.step(fx["real"].to(dev), noise_init=rec["noise_init"].to(dev), alphas=rec["alphas"])
     assert opt.Noise_Amps == pytest.approx(rec["noise_amps"], rel=1e-4)
-    for k in ("errD_real", "errD_fake", "gradient_penalty"):
-        assert_close(out[k], rec[k], 3e-3, "baseline." + k)  # after the first of two D updates: post-optimizer tolerance
-    assert_close(out["errG"], rec["errG"], 3e-3, "baseline.errG")
-    assert_close(out["rec_loss"], rec["rec_loss"], RTOL, "baseline.rec_loss")
-    assert_close(out["generated"], rec["generated"], RTOL, "baseline.generated")
-    assert_close(out["fake"], rec["fake"], RTOL, "baseline.fake")
-    gotG = flat_to_named(out["gradG_flat"], tr.arenaG, netG)
-    for k, g in rec["gradsG"].items():
-        if g is None:
-            assert float(gotG[k].abs().max()) == 0.0, k
-        else:
-            assert_close(gotG[k], g, 3e-3, "baseline.gradG." + k, atol=bn_bias_atol(k, rec["gradsG"], 1e-7))
-    lr = fx["opt"]["lr_g"]
+    from helpers import _bn_fed_bias, compare_step, compare_update
+    spread = fx["spread"][0]
+    got = dict(out)
+    got["gradsG"] = flat_to_named(out["gradG_flat"], tr.arenaG, netG)
+    got["gradsD"] = flat_to_named(out["gradD_flat"], tr.arenaD, netD)
+    compare_step(fname, rec, spread, got)
+    # post-step state by UPDATE (frozen stages bit-identical; trained blocks / head / tail at their group's learning rate)
+    gnames = dict(netG.named_parameters())
+    lr_of = {}
+    for n, p in gnames.items():
+        o, _ = tr.arenaG.range[id(p)]
+        hit = [g["lr"] for g in tr.optimizerG.groups if g["lo"] <= o < g["hi"]]
+        lr_of[n] = hit[0] if hit else None
     sdG, sdD = netG.state_dict(), netD.state_dict()
     for k, v in rec["G_after"].items():
-        assert_close(sdG[k].float(), v.float(), RTOL, "baseline.G_after." + k, atol=2 * lr)
+        if k in gnames:
+            sf = 0.05 if (lr_of[k] and spread["G_after"].get(k, 0.0) > lr_of[k] / 10) else 0.0
+            compare_update("baseline.G." + k, fx["G_init"][k], v, sdG[k], lr_of[k], sf, _bn_fed_bias(k, set(gnames)),
+                           first_step=(opt.Gsteps == 1))
+        elif k.endswith("num_batches_tracked"):
+            assert int(sdG[k]) == int(v), k
+        else:
+            assert_close(sdG[k].float(), v.float(), RTOL, "baseline.G_after." + k, atol=max(1e-6, 2 * spread["G_after"].get(k, 0.0)))
+    dnames = dict(netD.named_parameters())
     for k, v in rec["D_after"].items():
-        assert_close(sdD[k].float(), v.float(), RTOL, "baseline.D_after." + k, atol=4 * lr)
+        if k in dnames:
+            sf = 0.05 if spread["D_after"].get(k, 0.0) > opt.lr_d / 10 else 0.0
+            compare_update("baseline.D." + k, fx["D_init"][k], v, sdD[k], opt.lr_d, sf, _bn_fed_bias(k, set(dnames)),
+                           first_step=(opt.Dsteps == 1))
+        elif k.endswith("num_batches_tracked"):
+            assert int(sdD[k]) == int(v), k
+        else:
+            assert_close(sdD[k].float(), v.float(), RTOL, "baseline.D_after." + k, atol=max(1e-6, 2 * spread["D_after"].get(k, 0.0)))
 
 
 @pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step3d_vae_s1.pt"])

@@ -123,7 +123,9 @@ def _worker(rank, world, port, fname, outdir):
 
 
 @pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step3d_gan_s3.pt", 3), ("step3d_gan_s3_td2.pt", 4),
-                                         ("step3d_gan_s2_all.pt", 3), ("step2d_gan_s2.pt", 2), ("step3d_vae_s1.pt", 2)])
+                                         ("step3d_gan_s2_all.pt", 3), ("step2d_gan_s2.pt", 2), ("step3d_vae_s1.pt", 2),
+                                         # BASELINE configs[3]: 8 pyramid levels, one per rank on 8 ranks
+                                         ("step3d_gan_s7.pt", 8), ("step3d_gan_s7.pt", 5)])
 def test_level_pipeline_matches_single_process(fname, world):
     from helpers import assert_close
     from oracle import hpvg_oracle as O
@@ -133,6 +135,8 @@ def test_level_pipeline_matches_single_process(fname, world):
         got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(world)]
     lr = fx["opt"]["lr_g"]
     assert len(got[0]["parts"]) == min(world, fx["scale_idx"] + 1)
+    if world == fx["scale_idx"] + 1:
+        assert [tuple(p) for p in got[0]["parts"]] == [(k, k) for k in range(world)], "one pyramid level per rank"
     for r in range(world):
         assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
         for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss", "rec_vae_loss", "kl_loss"):
