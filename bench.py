@@ -25,17 +25,44 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-# collected separately and committed as profiles/r01_pmc_traffic_stage9.csv; bench.py cannot run the profiler itself.
-MEASURED_TRAFFIC_BYTES = {(2, 64, 13, 144, 256): 1.150e9}  # conv_mfma_kernel 9.77e8 + conv_fixup_kernel 1.73e8 (440 of 1976 tiles cut)
 
 
-CONFIG = "video"  # set by --config: "video" = BASELINE configs[2] (metric config), "image" = configs[1] (2-D path)
+def measured_traffic(shape):
+    """HBM bytes per launch of the dominant kernel at `shape`, from the rocprofv3 PMC passes committed under profiles/
+    (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, gfx950 x2 fetch correction: tools/pmc_summary.py writes
+    profiles/roofline_traffic.json beside the per-kernel csv).  bench.py cannot run the profiler itself; a shape the
+    profile does not cover yields None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for e in rec.get("entries", []):
+        if tuple(e["shape"]) == tuple(shape):
+            return e["bytes"], e["source"]
+    return None, None
+
+
+# --config: "video" = BASELINE configs[2] (the metric's config), "image" = configs[1] (2-D path), "video8" = configs[3]
+# (8 pyramid scales: --min-size 48; with --gpus N the level pipeline, one level per GPU at N = 8), "baseline" = configs[4]
+# (train_video_baselines.py --generator GeneratorSG, 8 scales; with --gpus N the stage pipeline)
+CONFIG = "video"
+WORKLOADS = {
+    "video": "train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2])",
+    "image": "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path)",
+    "video8": "train_video air_balloons 13f@256x144 --min-size 48 => 8 pyramid scales, vae_levels=3 B=2 nfc=64 (BASELINE configs[3])",
+    "baseline": "train_video_baselines --generator GeneratorSG 13f@256x144 --min-size 48 => 8 scales, B=2 nfc=64 (BASELINE configs[4])",
+}
 
 
 def video_opt(device, **kw):
     if CONFIG == "image":
         return image_opt(device, **kw)
+    if CONFIG == "video8":
+        return _video_opt(device, **dict(dict(min_size=48), **kw))
+    if CONFIG == "baseline":
+        # train_video_baselines.py:216-270 defaults (Dsteps 1, Gsteps 1, alpha 10, train-depth 1) + the config's generator
+        return _video_opt(device, **dict(dict(min_size=48, generator="GeneratorSG", Dsteps=1, Gsteps=1, alpha=10.0, nc_z=3), **kw))
     return _video_opt(device, **kw)
 
 
@@ -82,14 +109,18 @@ class _HipGeom:
 
 
 def build_gpu_stages(device, stages):
-    """One StageTrainer per pyramid stage with synthetic resident inputs (setup is outside the timed region)."""
+    """One StageTrainer per pyramid stage with synthetic resident inputs (setup is outside the timed region).
+    Returns [(stage, trainer, step callable, real, real_zero)]."""
     import copy
     from hp_vae_gan_amd import train as hp_train
     from hp_vae_gan_amd.modules import networks_2d, networks_3d
     torch.manual_seed(0)
     base = video_opt(device)
     shapes = stage_shapes(base, _HipGeom)
-    proto = (networks_3d if base.dims == 3 else networks_2d).GeneratorHPVAEGAN(base)
+    baseline = CONFIG == "baseline"
+    nets = networks_3d if base.dims == 3 else networks_2d
+    proto = getattr(nets, base.generator)(base)
+    z_init = None
     out = []
     for s in range(base.stop_scale + 1):
         if s > 0:
@@ -107,14 +138,35 @@ def build_gpu_stages(device, stages):
         g = torch.Generator().manual_seed(100 + s)
         real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
         real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
-        trainer = hp_train.StageTrainer(opt, netG)
-        out.append((s, trainer, real, real_zero))
+        if baseline:
+            # fixed reconstruction noise of the whole run (train_video_baselines.py:39-44), the same tensor at every stage
+            if z_init is None:
+                z_init = torch.randn(opt.batch_size, 3, *shapes[0], generator=torch.Generator().manual_seed(99)).to(device)
+            opt.Z_init = z_init
+            trainer = hp_train.BaselineStageTrainer(opt, netG)
+            step = (lambda tr, r: (lambda: tr.step(r)))(trainer, real)
+        else:
+            trainer = hp_train.StageTrainer(opt, netG)
+            step = (lambda tr, r, rz: (lambda: tr.step(r, rz)))(trainer, real, real_zero)
+        out.append((s, trainer, step, real, real_zero))
     return out, shapes
 
 
+# iteration GFLOP per stage of configs[2] as the reference executes it: the extrapolation rule for the
+# stages the CPU leg does not run
+REF_ITER_GFLOP = {0: 41, 1: 67, 2: 105, 3: 615, 4: 1081, 5: 1838, 6: 3925, 7: 6602, 8: 10805, 9: 27914}
+
+
+def cpu_iters(s):
+    """timed iterations of the CPU leg at stage s (after one warm-up): BASELINE.md section 4's plan within the bench's time
+    budget (~30 s of CPU work on the box's 16 threads)"""
+    return 20 if s <= 3 else (3 if s <= 5 else 1)
+
+
 def cpu_baseline(stages, threads):
-    """The CPU oracle (port of the reference path, oracle/hpvg_oracle.py) timed on the host: one warm-up and one timed
-    iteration per sampled stage, same shapes / hyper-parameters, torch CPU fp32 with `threads` threads."""
+    """The CPU oracle (port of the reference path, oracle/hpvg_oracle.py) timed on the host: one warm-up, then cpu_iters(s)
+    timed iterations per sampled stage, same shapes / hyper-parameters, torch CPU fp32 with `threads` threads.
+    Returns {stage: mean seconds per iteration}."""
     from oracle import hpvg_oracle as O
     from hp_vae_gan_amd.modules import networks_3d
     torch.set_num_threads(threads)
@@ -149,17 +201,6 @@ def cpu_baseline(stages, threads):
         real_zero = torch.rand(opt.batch_size, 3, *O.level_shape(0, opt, 3), generator=g) * 2 - 1 if s > 0 else real
         amps = [1] + [0.05] * s
         zshape = [opt.batch_size, opt.latent_dim, *O.level_shape(0, opt, 3)]
-
-        def noise_stream():
-            while True:
-                yield None
-
-        class Lazy:
-            """N(0,1) draws of whatever shape the oracle asks for next (shape inferred at use)."""
-
-            def __init__(self):
-                self.q = []
-
         adam_g, adam_d = {}, {}
 
         def one_iter():
@@ -169,17 +210,31 @@ def cpu_baseline(stages, threads):
             return O.train_step(PG, PD, opt, 3, s, real, real_zero, ni, noises, torch.rand(()), amps, adam_g, adam_d)
 
         one_iter()  # warm-up
+        n = cpu_iters(s)
         t0 = time.perf_counter()
-        one_iter()
-        per_stage[s] = time.perf_counter() - t0
+        for _ in range(n):
+            one_iter()
+        per_stage[s] = (time.perf_counter() - t0) / n
     return per_stage
+
+
+def parallelism_mode():
+    """N > 1 schedule: HPVG_PARALLELISM=levels|schedules; default: the level pipeline for configs[3] (the partition that
+    config names), the pass / sample / row-slab schedules of multigpu.py for configs[2]."""
+    env = os.environ.get("HPVG_PARALLELISM", "")
+    if env:
+        return env
+    return "levels" if CONFIG == "video8" else "schedules"
 
 
 def _parallelism(world):
     """What the ranks do (hp_vae_gan_amd/multigpu.py); the stage thresholds are the env knobs the runner reads."""
     if world == 1:
         return "single GPU"
-    if os.environ.get("HPVG_PARALLELISM", "") == "levels":
+    if CONFIG == "baseline":
+        return ("stage pipeline: contiguous GeneratorSG stages per rank (frozen stages forward-only; the newest stage + D on the last), "
+                "stage outputs sent forward point to point (%d ranks)" % world)
+    if parallelism_mode() == "levels":
         return "level pipeline: contiguous pyramid levels per rank (finest level + D on the last), level outputs sent forward, gradients back (%d ranks)" % world
     vae = "VAE stages: rank 0 alone (hipGraph replay); "
     pair = vae + "GAN stages: rec/rand generator passes on ranks 0/1 + discriminator work split over the batch"
@@ -199,15 +254,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--stages", type=str, default="0-9", help="pyramid stages in a step, e.g. 0-9 or 9")
+    ap.add_argument("--stages", type=str, default="all", help="pyramid stages in a step, e.g. 0-9 or 9 (default: every stage of the config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stages", type=str, default="0-5")
+    ap.add_argument("--cpu-stages", type=str, default="0-7",
+                    help="stages the CPU leg times (20 iterations at stages 0-3, 3 at 4-5, 1 at 6-7; 8-9 are extrapolated)")
     ap.add_argument("--graph-stages", type=str, default="0-8",
                     help="stages whose iteration is captured once and replayed as a hipGraph (single-GPU path; the stage "
                          "holding the roofline kernel always stays eager so that its launches can be bracketed by events); "
                          "'none' = every stage eager.  Measured r01: +52 % at stage 0, +8 % at stage 3, +2 % at stage 7")
-    ap.add_argument("--config", choices=["video", "image"], default="video",
-                    help="video = BASELINE configs[2] (the metric's config, default); image = configs[1] (2-D path)")
+    ap.add_argument("--config", choices=["video", "image", "video8", "baseline"], default="video",
+                    help="video = BASELINE configs[2] (the metric's config, default); image = configs[1] (2-D path); video8 = "
+                         "configs[3] (8 pyramid scales, --min-size 48; N > 1: level pipeline, one level per GPU at N = 8); "
+                         "baseline = configs[4] (train_video_baselines GeneratorSG, 8 scales; N > 1: stage pipeline)")
     args = ap.parse_args()
     global CONFIG
     CONFIG = args.config
@@ -216,6 +274,11 @@ def main():
         a, _, b = r.partition("-")
         return list(range(int(a), int(b or a) + 1))
 
+    if args.stages == "all":
+        from hp_vae_gan_amd import utils as _hu
+        _o = video_opt("cpu")
+        _hu.adjust_scales2image(_o.img_size, _o)
+        args.stages = "0-%d" % _o.stop_scale
     stages = parse(args.stages)
     # keep torch's CPU thread pool small: the host side only launches kernels; a 128-thread OpenMP pool spinning after
     # tiny CPU ops exhausts the box's CPU share and the launching thread gets throttled for ~75 ms at a time
@@ -244,23 +307,21 @@ def main():
 
     if world > 1:
         from hp_vae_gan_amd import multigpu
-        runner = multigpu.build_bench_runner(video_opt, stages, device, rank, world)
+        runner = multigpu.build_bench_runner(video_opt, stages, device, rank, world, config=CONFIG, mode=parallelism_mode())
     else:
         built, shapes = build_gpu_stages(device, stages)
 
         class Runner:
-            def step(self):
-                for s, trainer, real, real_zero in built:
-                    trainer.step(real, real_zero)
+            last = {}
 
             def timed_stage(self, idx):
-                s, trainer, real, real_zero = built[idx]
-                trainer.step(real, real_zero)
+                s, trainer, step, real, real_zero = built[idx]
+                self.last[s] = step()
                 return s
 
             def check_finite(self):
-                for s, trainer, _, _ in built:
-                    for k, v in trainer.last.items():
+                for s, out in self.last.items():
+                    for k, v in (out or {}).items():
                         if torch.is_tensor(v) and v.numel() <= 2 and not bool(torch.isfinite(v).all()):
                             raise RuntimeError("stage %d: %s is not finite after the timed iterations: %s" % (s, k, v))
 
@@ -275,11 +336,11 @@ def main():
     # hipGraph replay for the launch-bound small stages (single-GPU path): one eager iteration (noise-amplitude
     # calibration, workspace sizing), then capture.  The stage holding the roofline kernel stays eager so that the
     # kernel's launches can be bracketed by events.
-    graph_stages = [] if args.graph_stages == "none" else parse(args.graph_stages)
+    graph_stages = [] if args.graph_stages == "none" else [g for g in parse(args.graph_stages) if g < max(stages)]
     if world == 1:
-        for s, trainer, real, real_zero in built:
-            if s in graph_stages and s != max(stages):
-                trainer.step(real, real_zero)
+        for s, trainer, step, real, real_zero in built:
+            if s in graph_stages and s != max(stages) and hasattr(trainer, "enable_graph"):
+                step()
                 trainer.enable_graph(real, real_zero)
     # Stage-major order, as training proceeds (train_video.py:414-417: each stage runs its iterations before the next
     # stage starts): W warm-up then K timed iterations of every stage = K "steps" of one iteration per stage.
@@ -288,7 +349,8 @@ def main():
             runner.timed_stage(i)
     barrier()
     # ---- timed region: exactly K steps; the dominant kernel's launches are bracketed by HIP events on the launch stream
-    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == (3 if CONFIG == "video" else 1) and not g["flip"])
+    KT = 1 if CONFIG == "image" else 3
+    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == KT and not g["flip"])
     ops.set_kernel_timer(timer)
     stage_ev = {}
     import gc
@@ -315,25 +377,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the dominant kernel's launches, from every rank: on N > 1 the finest level's convs run on the rank(s) that own that
+    # level (the last rank of a pipeline), not necessarily on rank 0
+    by_shape = {k: v + (rank,) for k, v in timer.summary().items()}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {tuple(k): v for k, v in by_shape.items()})
+        by_shape = {}
+        for d in gathered:
+            for k, v in d.items():
+                if k not in by_shape or v[1] > by_shape[k][1]:
+                    by_shape[k] = v
+
     if rank == 0:
         nstage = len(stages)
         per_stage = {str(s): 1000.0 * args.steps / ev[0].elapsed_time(ev[1]) for s, ev in stage_ev.items()}
         # dominant kernel: the 64->64 3x3x3 implicit-GEMM conv at the finest resident stage
         roof = None
-        by_shape = timer.summary()
         if by_shape:
-            # finest level; among its launches the per-pass batch (the discriminator's B = 2 convs; the merged generator
-            # pass runs the same kernel at B = 4) - the shape the PMC traffic figure was measured on
-            key = max(by_shape, key=lambda k: (k[2] * k[3] * k[4], -k[0]))
-            ms, n = by_shape[key]
+            # finest level; among its launches the per-pass batch B = batch_size when some rank ran it (the discriminator's
+            # convs on one GPU and in the pipelines: the shape the PMC traffic figure was measured on; the merged generator
+            # pass runs the same kernel at B = 4, the batch-split schedules at B = 1)
+            key = max(by_shape, key=lambda k: (k[2] * k[3] * k[4], k[0] == 2, -k[0]))
+            ms, n, owner = by_shape[key]
             B, C, T, H, W = key
-            flops = 2.0 * B * 64 * 64 * (27 if CONFIG == "video" else 9) * T * H * W
+            flops = 2.0 * B * 64 * 64 * (9 * KT) * T * H * W
             achieved = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)" % ("3x3x3" if CONFIG == "video" else "3x3"),
+            traffic, traffic_src = measured_traffic(key)
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)" % ("3x3x3" if KT == 3 else "3x3"),
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": MEASURED_TRAFFIC_BYTES.get(tuple(key)),
-                    "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 27, "shape": list(key),
-                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops}
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 9 * KT, "shape": list(key),
+                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops, "rank": owner}
         cpu = None
         if not args.no_cpu_baseline and world == 1 and CONFIG == "video":
             cs = [s for s in parse(args.cpu_stages) if s in stages]
@@ -342,9 +417,20 @@ def main():
                 per = cpu_baseline(cs, threads)
                 tot = sum(per.values())
                 gpu_same = sum(1.0 / per_stage[str(s)] for s in cs)
+                # stages not run on the CPU: time = t(last measured stage) x iteration-GFLOP ratio
+                ref = max(cs)
+                est = {s: per[ref] * REF_ITER_GFLOP[s] / REF_ITER_GFLOP[ref] for s in stages if s not in per and s in REF_ITER_GFLOP}
+                full = None
+                if all(s in per or s in est for s in stages):
+                    full = round(len(stages) / (tot + sum(est.values())), 4)
                 cpu = {"value": round(len(cs) / tot, 4), "unit": "stage-iterations/s", "cores": threads, "kind": "port",
-                       "sample": "1 warm-up + 1 timed iteration of the oracle train step at stages %s (same shapes, B=2, fp32)" % cs,
+                       "sample": ("oracle train step (oracle/hpvg_oracle.py, torch CPU fp32, %d threads) at stages %s, same shapes as the GPU "
+                                  "run (B=2): 1 warm-up + %s timed iterations per stage; stages %s are NOT run: their time is "
+                                  "extrapolated as t(stage %d) x iteration-GFLOP ratio of SURVEY.md 8d" %
+                                  (threads, cs, {s: cpu_iters(s) for s in cs}, sorted(est), ref)),
                        "per_stage_it_s": {str(s): round(1.0 / t, 4) for s, t in per.items()},
+                       "extrapolated_it_s": {str(s): round(1.0 / t, 5) for s, t in est.items()},
+                       "full_sweep_estimate": full,
                        "gpu_value_same_sample": round(len(cs) / gpu_same, 3)}
         line = {
             "metric": "train iters/sec per pyramid scale, air_balloons 13f@144p",
@@ -352,13 +438,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("train_video air_balloons 13f@256x144 vae_levels=3 B=2 nfc=64 (BASELINE configs[2]); "
-                                    if CONFIG == "video" else
-                                    "train_image air_balloons.jpg 256x192 vae_levels=3 B=2 nfc=64 (BASELINE configs[1], 2-D path); ") +
-                                   "step = 1 train iteration at each pyramid stage %s" % args.stages,
-                       "stages": stages, "hipgraph_stages": [s for s in graph_stages if s in stages and s != max(stages)] if world == 1 else
-                       [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"
-                        and os.environ.get("HPVG_PARALLELISM", "") != "levels"],
+            "config": {"workload": WORKLOADS[CONFIG] + "; step = 1 train iteration at each pyramid stage %s" % args.stages,
+                       "stages": stages,
+                       "hipgraph_stages": ([s for s in graph_stages if s in stages and CONFIG != "baseline"] if world == 1 else
+                                           [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"
+                                            and parallelism_mode() != "levels" and CONFIG != "baseline"]),
                        "parallelism": _parallelism(world)},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
             "roofline": roof, "cpu_baseline": cpu,

@@ -479,8 +479,10 @@ class DistStageTrainer:
                 b.div_(n)
 
 
-def build_bench_runner(make_opt, stages, device, rank, world):
-    """bench.py's N>1 path: one DistStageTrainer per pyramid stage with synthetic resident inputs."""
+def build_bench_runner(make_opt, stages, device, rank, world, config="video", mode="schedules"):
+    """bench.py's N>1 path: one trainer per pyramid stage with synthetic resident inputs.
+    config "baseline": pipeline.BaselinePipelineTrainer (GeneratorSG stages over the ranks); otherwise mode "levels":
+    pipeline.LevelPipelineTrainer, mode "schedules": DistStageTrainer (pass / sample / row-slab splits)."""
     import copy
     from . import train as hp_train
     from . import utils as hu
@@ -489,8 +491,9 @@ def build_bench_runner(make_opt, stages, device, rank, world):
     base = make_opt(device)
     hu.adjust_scales2image(base.img_size, base)
     base.stop_scale_time = base.stop_scale
-    proto = networks_3d.GeneratorHPVAEGAN(base)
+    proto = getattr(networks_3d, getattr(base, "generator", "GeneratorHPVAEGAN"))(base)
     built = []
+    z_init = None
     for s in range(base.stop_scale + 1):
         if s > 0:
             proto.init_next_stage()
@@ -513,7 +516,18 @@ def build_bench_runner(make_opt, stages, device, rank, world):
         real = (torch.rand(opt.batch_size, 3, *shapes[s], generator=g) * 2 - 1).to(device)
         real_zero = (torch.rand(opt.batch_size, 3, *shapes[0], generator=g) * 2 - 1).to(device) if s > 0 else real
         opt.Z_init_size = [opt.batch_size, opt.latent_dim, *shapes[0]]
-        if os.environ.get("HPVG_PARALLELISM", "") == "levels":
+        if config == "baseline":
+            from . import pipeline
+            if netD is None:
+                torch.manual_seed(1000 + s)
+                netD = networks_3d.WDiscriminator3D(opt).to(device)
+            if z_init is None:
+                z_init = torch.randn(opt.batch_size, 3, *shapes[0], generator=torch.Generator().manual_seed(99)).to(device)
+            opt.Z_init = z_init
+            trainer = pipeline.BaselinePipelineTrainer(opt, netG, netD, pipeline.HipBaselinePipeBackend(opt))
+            built.append((s, trainer, real, None))
+            continue
+        if mode == "levels":
             # the north_star's partition (pipeline.py): contiguous levels per rank; bounded by the rank holding the finest
             # level + D (<= ~1.2x), which is why it is not the default schedule
             from . import pipeline
@@ -546,15 +560,10 @@ def build_bench_runner(make_opt, stages, device, rank, world):
     class Runner:
         n = len(built)
 
-        def step(self):
-            for s, trainer, real, real_zero in built:
-                if trainer is not None:
-                    trainer.step(real, real_zero)
-
         def timed_stage(self, idx):
             s, trainer, real, real_zero = built[idx]
             if trainer is not None:
-                self.last[s] = trainer.step(real, real_zero)
+                self.last[s] = trainer.step(real) if real_zero is None else trainer.step(real, real_zero)
             return s
 
         last = {}
@@ -574,3 +583,7 @@ def broadcast_module(net, src=0, group=None):
     """Hand a module trained on one rank (VAE stages) to the others: parameters and buffers, in state_dict order."""
     for t in list(net.parameters()) + list(net.buffers()):
         broadcast(t.data, src=src, group=group)
+    # written through `.data`: no version counter moved, so the conv kernels' packed-weight cache must be dropped by hand
+    if any(p.is_cuda for p in net.parameters()):
+        from . import ops
+        ops.weights_changed()

@@ -109,6 +109,8 @@ class HipPipeBackend:
             def clip_step(sq_total, max_norm):
                 ops.clip_scale_(arena.grad, sq_total, max_norm)
                 adam.step()
+
+            step = staticmethod(adam.step)     # no clipping (the baseline trainer)
         return _O
 
     def d_optimizer(self, netD, lr_d, beta1):
@@ -292,3 +294,188 @@ class LevelPipelineTrainer:
         if self.netD is not None:
             for t in list(self.netD.parameters()) + list(self.netD.buffers()):
                 broadcast(t.data, src=self.R - 1)
+        _weights_rewritten()
+
+
+def _weights_rewritten():
+    """Parameters were overwritten through `.data` (a broadcast): torch's version counters did not move, so the packed
+    copies the conv kernels cache per weight version (ops.pack_weight) must be dropped by hand."""
+    try:
+        from . import ops
+    except Exception:   # CPU-only test processes that never load the kernels library
+        return
+    ops.weights_changed()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: train_video_baselines.py --generator GeneratorSG with one pyramid stage per GPU.
+class HipBaselinePipeBackend(HipPipeBackend):
+    """Arithmetic of the baseline pipeline on the gfx950 kernels: level k = GeneratorSG.body[k]."""
+
+    def sg_levels(self, netG, x, amps, mode, start, stop):
+        return netG(x, amps, mode=mode, start=start, stop=stop)
+
+    def level_tensors(self, netG, level):
+        m = netG.body[level]
+        return list(m.parameters()), list(m.buffers())
+
+
+class BaselinePipelineTrainer:
+    """One stage of the SinGAN-3D baseline trainer (train.BaselineStageTrainer = train_video_baselines.py:93-173) with
+    GeneratorSG's stages spread over the ranks: contiguous stages per rank, the newest stage and the discriminator on the
+    last.  The stages below the newest `train_depth` are FROZEN (train_video_baselines.py:55-57), so their ranks only run
+    forwards - the 3-channel stage output (before the tanh) goes point to point to the next rank, twice per iteration
+    (random pass, reconstruction pass), and no gradient comes back unless a trained stage lives further down
+    (`--train-depth` > the last rank's share).  No gradient clipping in this trainer; every rank steps Adam for the trained
+    stages it owns.  step() returns the same loss scalars on every rank."""
+
+    def __init__(self, opt, netG, netD, backend):
+        self.opt, self.netG, self.netD, self.be = opt, netG, netD, backend
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        s = opt.scale_idx
+        if len(netG.body) != s + 1:
+            raise ValueError("generator has %d stages, stage index is %d" % (len(netG.body), s))
+        pad = opt.num_layer + 2
+        self.shapes = [backend.level_shape(k, 3) for k in range(s + 1)]
+        padded = [[d + 2 * pad for d in sh] for sh in self.shapes]   # the valid convs of a stage run on the padded volume
+        self.parts = partition_levels(level_costs(padded, opt.batch_size, True), self.world)
+        self.R = len(self.parts)
+        self.active = self.rank < self.R
+        self.dev = next(netG.parameters()).device
+        self.iteration = 0
+        self.lo_t = max(0, s + 1 - opt.train_depth)      # first trained stage
+        for block in netG.body[:-opt.train_depth]:
+            for p in block.parameters():
+                p.requires_grad = False
+        if not self.active:
+            return
+        self.a, self.b = self.parts[self.rank]
+        self.first, self.last = self.rank == 0, self.rank == self.R - 1
+        owned = set()
+        for k in range(self.a, self.b + 1):
+            owned.update(id(p) for p in backend.level_tensors(netG, k)[0])
+        blocks = list(netG.body[-opt.train_depth:])
+        groups = [(list(blk.parameters()), opt.lr_g * (opt.lr_scale ** (len(blocks) - 1 - i))) for i, blk in enumerate(blocks)]
+        self.optG = backend.g_optimizer(netG, owned, groups, opt.beta1)
+        self.optD = backend.d_optimizer(netD, opt.lr_d, opt.beta1) if self.last else None
+
+    def _flows(self, a):
+        """does a gradient cross the boundary below stage a?  Only when a trained stage lives below it."""
+        return a > 0 and self.lo_t < a
+
+    def _io_shape(self, level):
+        return (self.opt.batch_size, self.opt.nc_im, *self.shapes[level])
+
+    def _g_pass(self, mode, z, grad=True):
+        be, netG, amps = self.be, self.netG, self.opt.Noise_Amps
+        xin = None
+        if self.first:
+            x = be.sg_levels(netG, z, amps, mode, 0, self.b + 1)
+        else:
+            xin = torch.empty(self._io_shape(self.a - 1), dtype=torch.float32, device=self.dev)
+            recv(xin, src=self.rank - 1)
+            if grad and self._flows(self.a):
+                xin.requires_grad_(True)
+            x = be.sg_levels(netG, xin, amps, mode, self.a, self.b + 1)
+        if not self.last:
+            send(x.detach().contiguous(), dst=self.rank + 1)
+        return x, xin
+
+    def _bcast_scalars(self, vals, src):
+        if self.rank == src:
+            t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=self.dev)
+        else:
+            t = torch.zeros(len(vals), dtype=torch.float64, device=self.dev)
+        broadcast(t, src=src)
+        return [float(v) for v in t.tolist()]
+
+    def step(self, real, noise_init=None, alphas=None):
+        opt, be = self.opt, self.be
+        if self.iteration == 0:
+            if opt.scale_idx == 0:
+                opt.noise_amp = 1
+                opt.Noise_Amps.append(1)
+            else:
+                opt.Noise_Amps.append(0)
+                amp = 0.0
+                if self.active:
+                    # (the reference runs this pass with autograd enabled, train_video_baselines.py:117-122; nothing is
+                    # differentiated afterwards, so the numbers are those of a no_grad pass)
+                    with torch.no_grad():
+                        x, _ = self._g_pass("rec", opt.Z_init, grad=False)
+                        if self.last:
+                            amp = opt.noise_amp_init * float(torch.sqrt(be.mse(real, x)).item()) / opt.batch_size
+                amp = self._bcast_scalars([amp], self.R - 1)[0]
+                opt.noise_amp = amp
+                opt.Noise_Amps[-1] = amp
+        self.iteration += 1
+        names = ["errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"]
+        vals = [0.0] * len(names)
+        if self.active:
+            if noise_init is None and self.first:
+                noise_init = be.noise(opt.Z_init)
+            trains = self.lo_t <= self.b           # this rank holds a trained stage or hands gradients further down
+            netD = self.netD
+            fake = fake_in = None
+            for j in range(opt.Dsteps):
+                keep = (j == opt.Dsteps - 1)
+                if self.last:
+                    self.optD.zero()
+                    errD_real = be.wgan_mean(netD(real), -1.0)
+                if keep:
+                    fake, fake_in = self._g_pass("rand", noise_init, grad=trains)
+                else:
+                    with torch.no_grad():
+                        fake, fake_in = self._g_pass("rand", noise_init, grad=False)
+                if self.last:
+                    errD_fake = be.wgan_mean(netD(fake.detach()), 1.0)
+                    a = None if alphas is None else alphas[j]
+                    gp = be.grad_penalty(netD, real, fake, opt.lambda_grad, a if a is not None else torch.rand(1, 1))
+                    (errD_real + errD_fake + gp).backward()
+                    self.optD.step()
+            outs, leaves = [fake], [fake_in]
+            gen = None
+            if opt.alpha > 0:
+                gen, gen_in = self._g_pass("rec", opt.Z_init, grad=trains)
+                outs.append(gen)
+                leaves.append(gen_in)
+            self.optG.zero()
+            if self.last:
+                for p in netD.parameters():
+                    p.requires_grad_(False)
+                errG = be.wgan_mean(netD(fake), -1.0) * opt.disc_loss_weight
+                for p in netD.parameters():
+                    p.requires_grad_(True)
+                total = errG
+                rec_loss = 0.0
+                if gen is not None:
+                    rec_loss = opt.alpha * be.mse(gen, real)
+                    total = total + rec_loss
+                total.backward()
+                vals = [errD_real, errD_fake, gp, errG, rec_loss]
+            elif trains:
+                grads = []
+                for o in outs:
+                    g = torch.empty_like(o)
+                    recv(g, src=self.rank + 1)
+                    grads.append(g)
+                torch.autograd.backward(outs, grads)
+            if trains and not self.first and self._flows(self.a):
+                for leaf in leaves:
+                    send(leaf.grad if leaf.grad is not None else torch.zeros_like(leaf), dst=self.rank - 1)
+            if trains:
+                for _ in range(opt.Gsteps):
+                    self.optG.step()
+        got = self._bcast_scalars(vals, self.R - 1)
+        return dict(zip(names, got))
+
+    def broadcast_levels(self):
+        """End of a stage: every rank receives the owners' parameters and buffers."""
+        for r, (a, b) in enumerate(self.parts):
+            for k in range(a, b + 1):
+                params, buffers = self.be.level_tensors(self.netG, k)
+                for t in params + buffers:
+                    broadcast(t.data, src=r)
+        for t in list(self.netD.parameters()) + list(self.netD.buffers()):
+            broadcast(t.data, src=self.R - 1)
+        _weights_rewritten()

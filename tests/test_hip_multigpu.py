@@ -263,7 +263,9 @@ def _pipe_worker(rank, world, port, fname, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step3d_gan_s3_td2.pt", 3), ("step2d_gan_s2.pt", 2)])
+@pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step3d_gan_s3_td2.pt", 3), ("step2d_gan_s2.pt", 2),
+                                         # the 8-level pyramid of BASELINE configs[3] on 6 processes (a box admits 6 on its card)
+                                         ("step3d_gan_s7.pt", 6)])
 def test_level_pipeline_hip_matches_reference(fname, world):
     """pipeline.LevelPipelineTrainer with the real kernels: levels spread over 2 / 3 processes (sharing the box's GPU),
     level outputs forward, their gradients back, global clip norm - the reference's post-step parameters on every rank."""
@@ -287,3 +289,69 @@ def test_level_pipeline_hip_matches_reference(fname, world):
         for k, v in rec["D_after"].items():
             if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
                 assert_close(got[r]["D"][k], v, 1e-3, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+
+
+
+def _baseline_pipe_worker(rank, world, port, fname, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import NoiseFeed, hip_opt, load_golden
+    from hp_vae_gan_amd import pipeline
+    from hp_vae_gan_amd.modules import networks_3d
+    fx = load_golden(fname)
+    s = fx["scale_idx"]
+    dev = "cuda"
+    opt = hip_opt(fx["opt"], 3, s, dev)
+    netG = networks_3d.GeneratorSG(opt)
+    for _ in range(s):
+        netG.init_next_stage()
+    netG.load_state_dict(fx["G_init"])
+    netG.to(dev)
+    netD = networks_3d.WDiscriminator3D(opt)
+    netD.load_state_dict(fx["D_init"])
+    netD.to(dev)
+    opt.Noise_Amps = list(fx["noise_amps_init"])
+    opt.Z_init = fx["Z_init"].to(dev)
+    rec = fx["iters"][0]
+    tr = pipeline.BaselinePipelineTrainer(opt, netG, netD, pipeline.HipBaselinePipeBackend(opt))
+    netG.noise_source = NoiseFeed([t for k, t in enumerate(rec["noises"], 1) if tr.a <= k <= tr.b], dev)
+    out = tr.step(fx["real"].to(dev), noise_init=rec["noise_init"].to(dev), alphas=rec["alphas"])
+    tr.broadcast_levels()
+    torch.cuda.synchronize()
+    torch.save({"out": out, "amps": opt.Noise_Amps, "parts": tr.parts,
+                "G": {k: v.detach().cpu() for k, v in netG.state_dict().items()},
+                "D": {k: v.detach().cpu() for k, v in netD.state_dict().items()}}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 6])
+def test_baseline_stage_pipeline_hip_matches_reference(world):
+    """BASELINE configs[4] with the real kernels: pipeline.BaselinePipelineTrainer spreads GeneratorSG's 8 stages over 2 / 6
+    processes (sharing the box's GPU; frozen stages forward-only, the newest stage + critic on the last rank) and must land
+    on the reference's losses and post-step parameters on every rank (fixture baseline3d_sg_s7.pt)."""
+    from helpers import _bn_fed_bias, compare_update, load_golden
+    fname = "baseline3d_sg_s7.pt"
+    fx = load_golden(fname)
+    rec, spread = fx["iters"][0], fx["spread"][0]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_baseline_pipe_worker, args=(world, _free_port(), fname, d), nprocs=world, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    s = fx["scale_idx"]
+    lr_g, lr_d = fx["opt"]["lr_g"], fx["opt"]["lr_d"]
+    assert len(got[0]["parts"]) == world
+    pnames = set(k for k in rec["G_after"] if k.endswith((".weight", ".bias")))
+    for r in range(world):
+        assert got[r]["amps"] == pytest.approx(rec["noise_amps"], rel=1e-4)
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
+            want = float(rec[k])
+            assert got[r]["out"][k] == pytest.approx(want, rel=1e-3, abs=max(1e-7, 2 * spread.get(k, 0.0))), (r, k)
+        for k, v in rec["G_after"].items():
+            if k in pnames:
+                lr = lr_g if k.startswith("body.%d." % s) else None      # train_depth 1: only the newest stage moves
+                compare_update("rank%d.G.%s" % (r, k), fx["G_init"][k], v, got[r]["G"][k], lr, 0.0, _bn_fed_bias(k, pnames))
+        for k, v in rec["D_after"].items():
+            if k.endswith((".weight", ".bias", ".weight_orig")):
+                compare_update("rank%d.D.%s" % (r, k), fx["D_init"][k], v, got[r]["D"][k], lr_d)
