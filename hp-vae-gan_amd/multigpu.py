@@ -22,8 +22,14 @@ VAE stages (scale_idx < vae_levels) have a single generator pass with BatchNorm 
 identical step (noise broadcast from rank 0), which keeps the replicas in sync at no extra speed.
 
 BatchNorm running statistics / SN u,v of the generator are advanced only by the pass a rank executes (they never
-influence training: the reference keeps netG in train mode for every forward); `sync_buffers()` averages them at the
-end of a stage.
+influence training: the reference keeps netG in train mode for every forward) - but they are saved in checkpoints, so
+the single-GPU SEQUENCE is reproduced exactly: the reference updates every BatchNorm twice per iteration, rec pass first
+(r <- 0.9 r + 0.1 a), then rand pass (r <- 0.9 r + 0.1 b).  The generator's running statistics live in one flat buffer
+(optim.BufferArena); a rand-pass rank measures its own update 0.1 b = r_after - 0.9 r_before and sends it (one ~18 KB
+message per iteration) to its rec-pass peer, which applies r <- 0.9 r + 0.1 b after its own pass: the rec ranks hold the
+single-GPU running statistics at all times.  The encoder's spectral-norm u / v only ever move on the rec ranks (the rand
+pass does not encode).  `sync_buffers()` at the end of a stage broadcasts both from rank 0 and adds up the
+num_batches_tracked counts of the two passes.
 
 Four ranks ("quad" mode, late stages): the generator passes are ALSO split over the batch - rank q = 2*pass + sample,
 rec pass on ranks {0, 1}, rand pass on ranks {2, 3}, each on its own sample - with BatchNorm statistics exchanged inside
@@ -235,6 +241,35 @@ class DistStageTrainer:
         self.o = backend.optimizers(netG, netD if self.is_gan else None, g_groups, opt.lr_d, opt.beta1)
         self.iteration = 0
         self.dev = next(netG.parameters()).device
+        # running statistics of the generator's BatchNorms in one flat tensor (exchanged between the passes' ranks), and the
+        # forward counts at the start of the stage (see module docstring / sync_buffers)
+        from .optim import BufferArena
+        self.bn_stats = BufferArena(netG) if self.is_gan else None
+        self._flush_counters()
+        self._nbt0 = {n: b.clone() for n, b in netG.named_buffers() if not b.dtype.is_floating_point}
+        self.rand_rank = nwork // 2            # first rank of the rand pass (pair: 1, quad: 2, oct: 4)
+
+    # ---- running statistics: the rand pass's update, measured where it happens and applied where the sequence is kept
+    BN_KEEP = 0.9   # 1 - momentum of every BatchNorm on the path (networks_3d.py:54: torch default momentum 0.1)
+
+    def _flush_counters(self):
+        for m in self.netG.modules():
+            if hasattr(m, "flush_counter"):
+                m.flush_counter()
+
+    def _rand_stats_before(self):
+        return self.bn_stats.flat.clone() if (self.bn_stats is not None and self.bn_stats.flat is not None) else None
+
+    def _rand_stats_send(self, before, dst):
+        if before is not None:
+            send(self.bn_stats.flat - self.BN_KEEP * before, dst=dst)      # = momentum * (batch statistics of the rand pass)
+
+    def _rec_stats_merge(self, src):
+        if self.bn_stats is not None and self.bn_stats.flat is not None:
+            upd = torch.empty_like(self.bn_stats.flat)
+            recv(upd, src=src)
+            with torch.no_grad():
+                self.bn_stats.flat.mul_(self.BN_KEEP).add_(upd)
 
     # ---- tiny helpers
     def _bcast_float(self, value, src=0, group=None):
@@ -298,11 +333,14 @@ class DistStageTrainer:
             generated, _, _ = netG(real_zero, opt.Noise_Amps, mode="rec")
             fake_b = torch.empty_like(real[0:1])
             recv(fake_b, src=1)
+            self._rec_stats_merge(1)
         else:
             if noise_init is None:
                 noise_init = be.noise(torch.empty(opt.Z_init_size, device=self.dev))
+            before = self._rand_stats_before()
             fake, _ = netG(noise_init, opt.Noise_Amps, noise_init=noise_init, mode="rand")
             send(fake[0:1].detach().contiguous(), dst=0)
+            self._rand_stats_send(before, 0)
             fake_b = fake[1:2].detach().contiguous()
         real_b = real[r:r + 1].contiguous()
         # -- D step on this rank's batch sample (same alpha on both ranks, drawn on rank 0's CPU generator)
@@ -400,6 +438,7 @@ class DistStageTrainer:
                 generated, _, _ = netG(real_zero[b:b + 1].contiguous(), opt.Noise_Amps, mode="rec")
                 fake_b = torch.empty_like(real_b)
                 recv(fake_b, src=peer(1))
+                self._rec_stats_merge(peer(1))
                 errD_real = be.wgan_mean(netD(real_b), -1.0) * frac   # D forward 1 of the reference sequence
                 errD_fake = be.wgan_mean(netD(fake_b), 1.0) * frac    # D forward 2
                 (errD_real + errD_fake).backward()
@@ -408,9 +447,11 @@ class DistStageTrainer:
                 if noise_init is None:
                     noise_init = be.noise(torch.empty(opt.Z_init_size, device=self.dev))
                 z = noise_init[b:b + 1].contiguous()
+                before = self._rand_stats_before()
                 fake, _ = netG(z, opt.Noise_Amps, noise_init=z, mode="rand")
                 fake_b = fake.detach().contiguous()
                 send(fake_b, dst=peer(0))
+                self._rand_stats_send(before, peer(0))
                 be.advance_sn(netD, 2)                               # forwards 1 and 2 run on the rec ranks
                 gp = be.grad_penalty(netD, real_b, fake_b, opt.lambda_grad, a) * frac   # D forward 3
                 gp.backward()
@@ -469,14 +510,31 @@ class DistStageTrainer:
         return {"rec_vae_loss": rec_vae_loss.detach(), "kl_loss": kl_loss.detach(), "total_loss": total.detach()}
 
     def sync_buffers(self):
-        """Average the generator's buffers (BN running stats, SN u/v) over the working ranks at the end of a stage."""
-        n = self.nwork if (self.is_gan and self.world >= 2) else 1
-        if n == 1 or not self.active:
+        """End of a stage: every rank gets the single-GPU generator buffers.  BatchNorm running statistics and the
+        encoder's spectral-norm u / v are those of rank 0 (a rec-pass rank: it holds the sequential running statistics,
+        see the module docstring, and the only ranks that run the encoder are the rec ranks) - broadcast, never averaged
+        (the mean of an updated and a stale unit vector is not a unit vector); num_batches_tracked = start of the stage +
+        the forwards of the rec pass + those of the rand pass."""
+        if not self.is_gan or self.world < 2:
             return
-        for b in self.netG.buffers():
+        self._flush_counters()
+        for n, b in self.netG.named_buffers():
             if b.dtype.is_floating_point:
-                all_reduce(b, group=self.work)
-                b.div_(n)
+                broadcast(b, src=0)
+            else:
+                d = (b - self._nbt0[n]) if self.rank in (0, self.rand_rank) else torch.zeros_like(b)
+                all_reduce(d)
+                with torch.no_grad():
+                    b.copy_(self._nbt0[n] + d)
+
+    def finish_stage(self):
+        """sync_buffers() + hand the trained parameters to the ranks that idled through a GAN stage (world > working ranks)
+        and drop the packed-weight cache (parameters are written through .data)."""
+        self.sync_buffers()
+        if self.is_gan and self.world > self.nwork:
+            broadcast_module(self.netG, src=0)
+            if self.netD is not None:
+                broadcast_module(self.netD, src=0)
 
 
 def build_bench_runner(make_opt, stages, device, rank, world, config="video", mode="schedules"):

@@ -61,6 +61,33 @@ class ParamArena:
         ops.clip_scale_(self.grad, sq, max_norm, info)
 
 
+class BufferArena:
+    """Re-homes the floating-point buffers of `module` whose names end with `suffixes` (default: BatchNorm running
+    statistics) into ONE flat tensor (`flat`); the module's buffers become views of it, so kernels that update them in place
+    keep working and the whole set can be exchanged / combined between ranks as one tensor (multigpu.DistStageTrainer).
+    Build it after .to(device); values are kept."""
+
+    def __init__(self, module, suffixes=("running_mean", "running_var")):
+        items = []
+        for mod in module.modules():
+            for name, buf in mod._buffers.items():
+                if buf is not None and buf.dtype.is_floating_point and name.endswith(tuple(suffixes)):
+                    items.append((mod, name, buf))
+        self.items = items
+        total = sum(b.numel() for _, _, b in items)
+        self.flat = None
+        if not items:
+            return
+        self.flat = torch.empty(total, dtype=items[0][2].dtype, device=items[0][2].device)
+        o = 0
+        with torch.no_grad():
+            for mod, name, buf in items:
+                n = buf.numel()
+                self.flat[o:o + n].copy_(buf.reshape(-1))
+                mod._buffers[name] = self.flat[o:o + n].view(buf.shape)
+                o += n
+
+
 class FlatAdam:
     """torch.optim.Adam semantics (eps 1e-8, no weight decay, no amsgrad) over arena ranges, one lr per group."""
 

@@ -264,8 +264,9 @@ def _pipe_worker(rank, world, port, fname, outdir):
 
 
 @pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step3d_gan_s3_td2.pt", 3), ("step2d_gan_s2.pt", 2),
-                                         # the 8-level pyramid of BASELINE configs[3] on 6 processes (a box admits 6 on its card)
-                                         ("step3d_gan_s7.pt", 6)])
+                                         # the 8-level pyramid of BASELINE configs[3] on 5 processes (a box admits 6 on its
+                                         # card, and the test runner itself holds the GPU)
+                                         ("step3d_gan_s7.pt", 5)])
 def test_level_pipeline_hip_matches_reference(fname, world):
     """pipeline.LevelPipelineTrainer with the real kernels: levels spread over 2 / 3 processes (sharing the box's GPU),
     level outputs forward, their gradients back, global clip norm - the reference's post-step parameters on every rank."""
@@ -327,9 +328,9 @@ def _baseline_pipe_worker(rank, world, port, fname, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 6])
+@pytest.mark.parametrize("world", [2, 5])
 def test_baseline_stage_pipeline_hip_matches_reference(world):
-    """BASELINE configs[4] with the real kernels: pipeline.BaselinePipelineTrainer spreads GeneratorSG's 8 stages over 2 / 6
+    """BASELINE configs[4] with the real kernels: pipeline.BaselinePipelineTrainer spreads GeneratorSG's 8 stages over 2 / 5
     processes (sharing the box's GPU; frozen stages forward-only, the newest stage + critic on the last rank) and must land
     on the reference's losses and post-step parameters on every rank (fixture baseline3d_sg_s7.pt)."""
     from helpers import _bn_fed_bias, compare_update, load_golden

@@ -276,6 +276,25 @@ def _single_process(fname):
     return fx, out, PG, PD, amps
 
 
+def _check_generator_buffers(fname, got, PG, nranks):
+    """After sync_buffers every rank holds the SINGLE-GPU generator buffers: BatchNorm running statistics follow the
+    reference's rec-then-rand update sequence, the encoder's spectral-norm u / v are the rec pass's (unit vectors),
+    num_batches_tracked counts both passes."""
+    from helpers import assert_close
+    from oracle import hpvg_oracle as O
+    for r in range(nranks):
+        for k, v in PG.items():
+            if O.is_param(k):
+                continue
+            mine = got[r]["G"][k]
+            if k.endswith("num_batches_tracked"):
+                assert int(mine) == int(v), "%s.rank%d.%s: %d vs %d" % (fname, r, k, int(mine), int(v))
+            else:
+                assert_close(mine, v.detach(), 1e-5, "%s.rank%d.G.%s" % (fname, r, k), atol=1e-6)
+            if k.endswith(("weight_u", "weight_v")):
+                assert abs(float(mine.norm()) - 1.0) < 1e-5, "%s.rank%d.%s is not a unit vector" % (fname, r, k)
+
+
 @pytest.mark.parametrize("fname,world", [("step3d_gan_s3.pt", 2), ("step2d_gan_s2.pt", 3), ("step3d_vae_s1.pt", 2)])
 def test_distributed_step_matches_single_process(fname, world):
     from helpers import assert_close
@@ -297,6 +316,7 @@ def test_distributed_step_matches_single_process(fname, world):
             for k, v in PD.items():
                 if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
                     assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    _check_generator_buffers(fname, got, PG, 2)
     # the two working ranks hold bit-identical replicas after the step
     for k in got[0]["G"]:
         if O.is_param(k):
@@ -328,6 +348,7 @@ def test_quad_step_matches_single_process(fname, world):
         for k, v in PD.items():
             if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
                 assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    _check_generator_buffers(fname, got, PG, 4)
     for r in range(1, 4):
         for k in got[0]["G"]:
             if O.is_param(k):
@@ -360,6 +381,7 @@ def test_oct_step_matches_single_process(fname, slab_levels):
         for k, v in PD.items():
             if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
                 assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+    _check_generator_buffers(fname, got, PG, 8)
     for r in range(1, 8):
         for k in got[0]["G"]:
             if O.is_param(k):
