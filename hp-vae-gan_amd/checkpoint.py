@@ -5,8 +5,15 @@ rule (train_video.py:399-412, 47-52).  Files are plain torch.save dicts:
   netD_<s>.pth    {'scale', 'state_dict', 'optimizer'}
   Noise_Amps.pth  {'data': [...]}
 
-state_dict keys are identical to the reference's, so checkpoints interchange in both directions.
-Only tensors / python scalars are written; load with weights_only=True."""
+state_dict keys are identical to the reference's and 'optimizer' is torch.optim.Adam's own
+state_dict layout (optim.FlatAdam.state_dict: per-parameter step / exp_avg / exp_avg_sq on the CPU, parameters numbered
+group by group), so checkpoints interchange in both directions (the reference never reloads the optimizer state:
+train_video.py:399-412 restores weights and noise amplitudes only).  Only tensors / python scalars are written; load with
+weights_only=True.
+
+hipGraph note (train.train): the switch to graph replay after two eager iterations runs ONE more real iteration on the
+batch at hand as the capture warm-up (it counts towards niter), and from then on the gradient penalty's alpha comes from
+the device generator instead of the CPU generator - same distribution, a different stream than the reference's."""
 import os
 
 import torch

@@ -102,7 +102,10 @@ class FlatAdam:
             if not params:
                 continue
             lo, hi = arena.span(params)
-            self.groups.append({"lo": lo, "hi": hi, "lr": lr,
+            # (offset inside the group, numel, shape) per parameter, in the group's own order: state_dict() hands the
+            # moments out per parameter, as torch.optim.Adam does
+            layout = [(arena.range[id(p)][0] - lo, p.numel(), tuple(p.shape)) for p in params]
+            self.groups.append({"lo": lo, "hi": hi, "lr": lr, "layout": layout,
                                 "m": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device),
                                 "v": torch.zeros(hi - lo, dtype=torch.float32, device=arena.flat.device)})
         self.t = 0
@@ -110,12 +113,34 @@ class FlatAdam:
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=arena.flat.device)
 
     def step(self):
-        self.t += 1
+        self.t += 1   # host mirror (eager steps only; replays of a captured step advance t_dev alone: see steps())
         ops.counter_inc_(self.t_dev)
         for g in self.groups:
             lo, hi = g["lo"], g["hi"]
             ops.adam_step_(self.arena.flat[lo:hi], self.arena.grad[lo:hi], g["m"], g["v"], g["lr"], self.betas[0], self.betas[1],
                            self.eps, self.t, self.t_dev)
 
+    def steps(self):
+        """Optimizer steps taken so far - read from the device counter (the only one hipGraph replays advance)."""
+        return int(self.t_dev.item())
+
     def state_dict(self):
-        return {"t": self.t, "groups": [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in g.items()} for g in self.groups]}
+        """torch.optim.Adam's state_dict layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}),
+        CPU tensors, parameters numbered group by group in the order the groups were given - what the reference writes
+        into netG.pth / netD_<s>.pth (train_video.py:246-258); torch.optim.Adam.load_state_dict accepts it for an optimizer
+        built over the same groups."""
+        t = self.steps()
+        state, param_groups, idx = {}, [], 0
+        for g in self.groups:
+            ids = []
+            m, v = g["m"].detach().cpu(), g["v"].detach().cpu()
+            for o, n, shape in g["layout"]:
+                if t > 0:
+                    state[idx] = {"step": torch.tensor(float(t)), "exp_avg": m[o:o + n].view(shape).clone(),
+                                  "exp_avg_sq": v[o:o + n].view(shape).clone()}
+                ids.append(idx)
+                idx += 1
+            param_groups.append({"lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                                 "params": ids})
+        return {"state": state, "param_groups": param_groups}

@@ -356,3 +356,34 @@ def test_baseline_stage_pipeline_hip_matches_reference(world):
         for k, v in rec["D_after"].items():
             if k.endswith((".weight", ".bias", ".weight_orig")):
                 compare_update("rank%d.D.%s" % (r, k), fx["D_init"][k], v, got[r]["D"][k], lr_d)
+
+
+def _bcast_pack_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from hp_vae_gan_amd import multigpu
+    from hp_vae_gan_amd.modules import _nets
+    torch.manual_seed(10 + rank)                      # different weights on the two ranks
+    conv = _nets.Conv(3, 8, 8).to("cuda")
+    x = torch.randn(1, 8, 3, 6, 7, generator=torch.Generator().manual_seed(5)).to("cuda")
+    with torch.no_grad():
+        before = conv(x).cpu()                        # packs this rank's weight (ops.pack_weight cache)
+        multigpu.broadcast_module(conv, src=0)        # overwrites the parameters through .data: no version counter moves
+        after = conv(x).cpu()
+    torch.save({"before": before, "after": after}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_module_drops_packed_weights():
+    """Parameters written through `.data` (multigpu.broadcast_module, pipeline.broadcast_levels) leave torch's version
+    counter alone; the conv must not keep using the weights it packed before the broadcast."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bcast_pack_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(2)]
+    assert not torch.allclose(got[0]["before"], got[1]["before"])
+    assert torch.equal(got[0]["after"], got[0]["before"])
+    assert torch.equal(got[1]["after"], got[0]["after"]), "rank 1 still convolves with its pre-broadcast packed weights"

@@ -168,3 +168,38 @@ def test_no_memset_or_memcpy_nodes_in_the_kernels_sources():
     for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
         code = re.sub(r"//[^\n]*", "", open(path).read())           # comments may mention them
         assert "hipMemsetAsync" not in code and "hipMemcpyAsync" not in code and "hipMemset(" not in code, path
+
+
+def test_flat_adam_state_dict_is_torch_adams(tmp_path):
+    """optim.FlatAdam.state_dict() is torch.optim.Adam's layout: an Adam built over the same groups loads it, the moments
+    land on the right parameters, the step count is the device counter's (the only one hipGraph replays advance), and the
+    dict survives torch.save / weights_only load (what checkpoint.stage_checkpoint writes as 'optimizer')."""
+    from hp_vae_gan_amd import optim as hp_optim
+    from hp_vae_gan_amd import train as hp_train
+    fx = load_golden("step3d_gan_s3_td2.pt")     # two trained blocks with different learning rates
+    opt = opt_from(fx["opt"], scale_idx=3)
+    G = networks_3d.GeneratorHPVAEGAN(opt)
+    for _ in range(3):
+        G.init_next_stage()
+    arena = hp_optim.ParamArena(G)
+    groups = [(list(ps), lr) for ps, lr in hp_train.generator_param_groups(opt, G)]
+    adam = hp_optim.FlatAdam(arena, groups, betas=(0.5, 0.999))
+    assert adam.state_dict()["state"] == {}          # nothing stepped yet: torch's Adam has no state either
+    g = torch.Generator().manual_seed(3)
+    for grp in adam.groups:
+        grp["m"].copy_(torch.randn(grp["m"].shape, generator=g))
+        grp["v"].copy_(torch.rand(grp["v"].shape, generator=g))
+    adam.t_dev.fill_(7)                              # seven replayed steps: the host mirror adam.t never saw them
+    sd = adam.state_dict()
+    torch.save(sd, str(tmp_path / "opt.pt"))
+    sd = torch.load(str(tmp_path / "opt.pt"), weights_only=True)
+    ref = torch.optim.Adam([{"params": ps, "lr": lr} for ps, lr in groups], lr=opt.lr_g, betas=(0.5, 0.999))
+    ref.load_state_dict(sd)
+    assert [pg["lr"] for pg in ref.param_groups] == [lr for _, lr in groups] and len(groups) == 2 and groups[0][1] != groups[1][1]
+    for (ps, _), grp in zip(groups, adam.groups):
+        for p in ps:
+            o, n = arena.range[id(p)]
+            st = ref.state[p]
+            assert float(st["step"]) == 7.0
+            assert torch.equal(st["exp_avg"], grp["m"][o - grp["lo"]:o - grp["lo"] + n].view(p.shape))
+            assert torch.equal(st["exp_avg_sq"], grp["v"][o - grp["lo"]:o - grp["lo"] + n].view(p.shape))
