@@ -77,6 +77,7 @@ _SIGS = {
     "hpvg_clip_scale_f32": [P, L, P, F, P, P],
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
     "hpvg_counter_inc_i32": [P, P],
+    "hpvg_graph_node_census": [P, P, I],
 }
 _SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 

@@ -16,6 +16,19 @@ from .modules.losses import kl_criterion, mse_loss, wgan_mean
 from .modules.utils import calc_gradient_penalty
 
 
+_NODE_TYPES = ["kernel", "memcpy", "memset", "host", "graph", "empty", "wait_event", "event_record", "ext_sem_signal",
+               "ext_sem_wait", "mem_alloc", "mem_free", "memcpy_from_symbol", "memcpy_to_symbol", "batch_mem_op", "other"]
+
+
+def graph_node_census(graph):
+    """{node type: count} of a torch.cuda.CUDAGraph captured with keep_graph=True (hpvg_graph_node_census)."""
+    import ctypes
+    from .lib import call
+    counts = (ctypes.c_int * len(_NODE_TYPES))()
+    call("hpvg_graph_node_census", ctypes.c_void_p(graph.raw_cuda_graph()), counts, len(_NODE_TYPES))
+    return {name: int(c) for name, c in zip(_NODE_TYPES, counts)}
+
+
 def _networks(opt):
     return networks_3d if getattr(opt, 'dims', 3) == 3 else networks_2d
 
@@ -104,7 +117,7 @@ class StageTrainer:
             self._step_eager(self._g_real, self._g_rz)  # warm-up on the capture stream's side (allocator, workspaces)
         torch.cuda.current_stream().wait_stream(side)
         it = self.iteration
-        self._graph = torch.cuda.CUDAGraph()
+        self._graph = torch.cuda.CUDAGraph(keep_graph=True)   # keep the hipGraph_t: its nodes are inspected below
         # host-side state that python advances while it records the iteration: BatchNorm forward counts (replays must add
         # the same amounts, the capture itself must not count)
         bns = [m for net in (self.netG, self.netD) if net is not None for m in net.modules() if hasattr(m, 'pending_batches')]
@@ -113,6 +126,14 @@ class StageTrainer:
         with torch.cuda.graph(self._graph):
             self._g_out = self._step_eager(self._g_real, self._g_rz)
         ops.weights_changed()
+        self.graph_nodes = graph_node_census(self._graph)
+        bad = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "empty", "event_record", "wait_event") and v}
+        if bad:
+            # memcpy / memset nodes are not reliably ordered against kernel nodes on this runtime (replays
+            # trained NaNs); whatever put them there (a torch fill / slice-backward / pad lowering) must become a kernel
+            self._graph = None
+            raise RuntimeError("the captured iteration holds non-kernel graph nodes %s (of %s): refusing to replay it" % (bad, self.graph_nodes))
+        self._graph.instantiate()
         self._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
         for m, b in zip(bns, before):
             m.pending_batches = b

@@ -169,6 +169,11 @@ int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, flo
                        int step, const int* step_dev, void* stream);
 int hpvg_counter_inc_i32(int* counter, void* stream);
 
+/* ---- hipGraph replay of the iteration (host only): node census of a captured graph, counts[t] per hipGraphNodeType t
+ * (0 kernel, 1 memcpy, 2 memset, ...; child graphs included).  The trainers refuse a captured iteration that holds
+ * memcpy / memset nodes: those are not reliably ordered against kernel nodes on this runtime. */
+int hpvg_graph_node_census(void* graph, int* counts, int ntypes);
+
 #ifdef __cplusplus
 }
 #endif
