@@ -61,6 +61,7 @@ struct ConvFwdArgs {
   const float* bias;
   const float* in_scale;
   const float* in_shift;
+  const float* mask;  // optional [B][Cout][T][H][W]: y *= (mask > 0 ? 1 : 0.2) - leaky_relu_backward fused into the backward-data conv
   float* y;
   int B, Cin, Cout, T, H, W;
   // tile = `L` consecutive positions of the row-flattened band (W split into ntw bands of Tw columns, LDS row stride
@@ -372,7 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
           if (co < a.Cout) {
             float val = acc[m][i][e] + bias_r[m][e];
             if (a.out_lrelu) val = hpvg_lrelu(val);
-            a.y[((long)b * a.Cout + co) * a.T * HW + sp] = val;
+            const long oi = ((long)b * a.Cout + co) * a.T * HW + sp;
+            if (a.mask) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+            a.y[oi] = val;
           }
         }
       }
@@ -424,7 +427,9 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
     float val = v[e];
     if (a.bias) val += a.bias[co];
     if (a.out_lrelu) val = hpvg_lrelu(val);
-    a.y[((long)tc.b * a.Cout + co) * a.T * HW + sp] = val;
+    const long oi = ((long)tc.b * a.Cout + co) * a.T * HW + sp;
+    if (a.mask) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+    a.y[oi] = val;
   }
 }
 
@@ -548,7 +553,9 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const ConvFwdArgs a
         for (int dw = 0; dw < 3; ++dw) v += P[(o * 9 + dh * 3 + dw) * pitch + (hh + dh) * RS + ww + dw];
       if (a.bias) v += a.bias[o];
       if (a.out_lrelu) v = hpvg_lrelu(v);
-      a.y[((long)b * a.Cout + o) * a.T * HW + sp] = v;
+      const long oi = ((long)b * a.Cout + o) * a.T * HW + sp;
+      if (a.mask) v *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+      a.y[oi] = v;
     }
   }
 }
@@ -929,11 +936,13 @@ int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* 
 // y[b][o][t][h][w] = bias[o] + sum_{c,tap} Wp[o][c][tap] * f(x)[b][c][t+dt-pt][h+dh-1][w+dw-1]
 // f = identity, or (in_scale[c]*x + in_shift[c]) followed by LeakyReLU(0.2) when in_lrelu (zero padding
 // is applied AFTER f, as in the reference where f is the previous block's BatchNorm+LeakyReLU output).
+// out_mask (optional, the output's shape): y *= (out_mask > 0 ? 1 : 0.2) after bias / LeakyReLU - the leaky_relu_backward of
+// the layer below, fused into this conv when it runs as that layer's consumer's backward-data pass.
 // ws / ws_bytes: hpvg_conv_fwd_ws_bytes() of scratch enables the stream-K schedule; with ws = NULL (or too small)
 // the same kernel runs one workgroup per tile.
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
-                      int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
-                      int W, int KT, void* stream) {
+                      int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
+                      int Cout, int T, int H, int W, int KT, void* stream) {
   if (!x || !wp || !y) return HPVG_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
@@ -952,7 +961,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
     ntl = B * T * p.nrange * p.ntw * p.gridy;
   }
   ConvFwdArgs a;
-  a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.y = y;
+  a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.mask = out_mask; a.y = y;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.L = p.L; a.qstride = p.qstride; a.nrange = p.nrange; a.ntw = p.ntw; a.nblocks = p.nblocks;
   a.nchunk = nchunk;

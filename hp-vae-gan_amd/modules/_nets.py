@@ -40,11 +40,13 @@ class Conv(nn.Module):
     # multi-GPU: slab.Halo when this layer's level is cut into row slabs over neighbouring ranks (multigpu.py sets it)
     halo = None
 
-    def forward(self, x, act=False):
+    def forward(self, x, act=False, in_act=False):
+        """in_act: x is the activated output of a spectral-norm block that left its LeakyReLU backward to this conv
+        (ops.Conv: the mask rides in this layer's backward-data epilogue)."""
         if self.halo is not None:
             assert self.padding == 1, "row slabs are implemented for the 'same' convolutions of the HP-VAE-GAN path"
-            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, self.weight, self.bias, act))
-        y = ops.Conv.apply(x, self.weight, self.bias, act)
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, self.weight, self.bias, act, in_act))
+        y = ops.Conv.apply(x, self.weight, self.bias, act, in_act)
         return y if self.padding == 1 else crop_border(y)
 
 
@@ -84,13 +86,14 @@ class SNConv(nn.Module):
 
     halo = None  # as Conv.halo
 
-    def forward(self, x, act=False, weight=None):
+    def forward(self, x, act=False, weight=None, in_act=False, mask_by_consumer=False):
         """weight: the effective weight when the caller computed it for all of its spectral-norm layers at once
-        (sn_weights below); None: this layer runs its own power iteration."""
+        (sn_weights below); None: this layer runs its own power iteration.  in_act / mask_by_consumer: see ops.Conv
+        (the LeakyReLU backward of a chain of activated convs rides in the consumer's backward-data epilogue)."""
         w = weight if weight is not None else self.effective_weight()
         if self.halo is not None:
-            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act))
-        return ops.Conv.apply(x, w, self.bias, act)
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act, in_act, mask_by_consumer))
+        return ops.Conv.apply(x, w, self.bias, act, in_act, mask_by_consumer)
 
 
 def sn_weights(convs):
@@ -174,10 +177,10 @@ class ConvBlock(nn.Module):
         self.has_bn = bn
         self.act = act
 
-    def forward(self, x):
+    def forward(self, x, in_act=False):
         if self.has_bn:
-            return self.norm(self.conv(x), lrelu=self.act is not None)
-        return self.conv(x, act=self.act is not None)
+            return self.norm(self.conv(x, in_act=in_act), lrelu=self.act is not None)
+        return self.conv(x, act=self.act is not None, in_act=in_act)
 
 
 class ConvBlockSN(nn.Module):
@@ -193,8 +196,9 @@ class ConvBlockSN(nn.Module):
         self.conv = SNConv(dims, in_channel, out_channel, ker_size, padding, stride)
         self.act = act
 
-    def forward(self, x, weight=None):
-        return self.conv(x, act=self.act is not None, weight=weight)
+    def forward(self, x, weight=None, in_act=False, mask_by_consumer=False):
+        return self.conv(x, act=self.act is not None, weight=weight, in_act=in_act,
+                         mask_by_consumer=mask_by_consumer and self.act is not None)
 
 
 class FeatureExtractor(nn.Sequential):
@@ -209,10 +213,13 @@ class FeatureExtractor(nn.Sequential):
             self.add_module('conv_block_{}'.format(i + 1), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
         self.add_module('conv_block_{}'.format(num_blocks), ConvBlockSN(dims, out_channel, out_channel, ker_size, padding, stride))
 
-    def forward(self, x):
+    def forward(self, x, mask_by_consumer=False):
+        """mask_by_consumer: every consumer of the returned features is a conv called with in_act=True (EncodeVAE's mu /
+        logvar heads), so the last block leaves its LeakyReLU backward to them like the inner blocks do."""
         blocks = list(self)
-        for blk, w in zip(blocks, sn_weights([b.conv for b in blocks])):   # all power iterations in one launch
-            x = blk(x, weight=w)
+        last = len(blocks) - 1
+        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
+            x = blk(x, weight=w, in_act=i > 0, mask_by_consumer=(i < last or mask_by_consumer))
         return x
 
 
@@ -231,8 +238,8 @@ class EncodeVAE(nn.Module):
         self.logvar = ConvBlock(dims, opt.nfc, output_dim, opt.ker_size, opt.ker_size // 2, 1, bn=False, act=None)
 
     def forward(self, x):
-        features = self.features(x)
-        return self.mu(features), self.logvar(features)
+        features = self.features(x, mask_by_consumer=True)
+        return self.mu(features, in_act=True), self.logvar(features, in_act=True)
 
 
 def _seven_conv_stack(dims, in_channel, N, opt, padding):
@@ -261,9 +268,11 @@ class WDiscriminator(nn.Module):
 
     def forward(self, x):
         blocks = [self.head] + list(self.body)
-        for blk, w in zip(blocks, sn_weights([b.conv for b in blocks])):   # all power iterations in one launch
-            x = blk(x, weight=w)
-        return self.tail(x)
+        # every activation of the chain has exactly one consumer, the next conv: its LeakyReLU backward rides in that conv's
+        # backward-data epilogue (ops.Conv in_act / mask_by_consumer) instead of being a pass of its own
+        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
+            x = blk(x, weight=w, in_act=i > 0, mask_by_consumer=True)
+        return self.tail(x, in_act=True)
 
 
 class GeneratorHPVAEGAN(nn.Module):

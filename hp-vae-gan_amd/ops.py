@@ -157,8 +157,9 @@ def prepack_weights(ws, flips=(False, True)):
         _pack_cache[key] = (w._version, w.detach(), wp)
 
 
-def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False):
-    """y = conv(f(x), w) (+bias); flip=True runs the backward-data conv of the layer weight w."""
+def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False, out_mask=None):
+    """y = conv(f(x), w) (+bias); flip=True runs the backward-data conv of the layer weight w.
+    out_mask (shaped like y): y *= (out_mask > 0 ? 1 : 0.2) in the kernel's epilogue (leaky_relu_backward of the layer below)."""
     x = _c(x)
     B, C, T, H, W = geom(x)
     KT = _kt(w.shape)
@@ -178,9 +179,11 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
         timed[0].record()
     nws = call("hpvg_conv_fwd_ws_bytes", B, cin_k, cout_k, T, H, W, KT)
     ws = workspace(nws, x.device) if nws else None
+    if out_mask is not None and tuple(out_mask.shape) != tuple(shape):
+        raise RuntimeError("conv: out_mask has shape %s, the output %s" % (tuple(out_mask.shape), tuple(shape)))
     call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
-         1 if out_lrelu else 0, ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT,
-         stream())
+         1 if out_lrelu else 0, ptr(_c(out_mask)) if out_mask is not None else None, ptr(ws),
+         ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT, stream())
     if timed is not None:
         timed[1].record()
         _kernel_timer.events.append(((B, cin_k, T, H, W), timed[0], timed[1]))
@@ -297,13 +300,22 @@ class ChannelSum(Function):
 
 
 class Conv(Function):
-    """y = conv3x3(x, w) + b, optionally followed by LeakyReLU(0.2) (ConvBlock3DSN / plain tails)."""
+    """y = conv3x3(x, w) + b, optionally followed by LeakyReLU(0.2) (ConvBlock3DSN / plain tails).
+
+    Chains of activated convs (the spectral-norm critic and encoder: networks_3d.py:59-70,163-181) hand the LeakyReLU's
+    backward mask from the PRODUCER of an activation to its CONSUMER, where it costs nothing: the consumer's backward-data
+    conv computes the gradient w.r.t. the activated tensor - its own saved input - and multiplies by the mask in its
+    epilogue (conv_fwd_raw(out_mask=)); leaky_relu_backward as a pass of its own (three tensor sweeps per layer and
+    backward chain) is gone.
+      in_act       : x is the output of a Conv(act=True, out_masked_by_consumer=True): dx is masked with lrelu'(x) here
+      mask_by_consumer : (with act) every consumer of y is such a Conv, so this backward must NOT mask dy again."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, in_act=False, mask_by_consumer=False):
         y = conv_fwd_raw(x, w, b, out_lrelu=act)
-        ctx.save_for_backward(x, w, y if act else None, b)
-        ctx.act = act
+        own_mask = act and not mask_by_consumer
+        ctx.save_for_backward(x, w, y if own_mask else None, b)
+        ctx.own_mask, ctx.in_act = own_mask, in_act
         ctx.has_bias = b is not None
         return y
 
@@ -311,33 +323,36 @@ class Conv(Function):
     def backward(ctx, dy):
         x, w, y, b = ctx.saved_tensors
         dy = _c(dy)
-        if ctx.act:
+        if ctx.own_mask:
             dy = LReLUMaskMul.apply(dy, y)
         params = not inputs_only.active
-        dx = ConvBwdData.apply(dy, w) if ctx.needs_input_grad[0] else None
+        dx = ConvBwdData.apply(dy, w, x if ctx.in_act else None) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(dy, x, w) if (ctx.needs_input_grad[1] and params) else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and params:
             slot = grad_slot(b)
             db = channel_sum_raw(dy, into=slot) if slot is not None else ChannelSum.apply(dy)
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
 
 
 class ConvBwdData(Function):
-    """dx = conv(dy, flip/transpose(w)): backward-data of a stride-1 'same' conv."""
+    """dx = conv(dy, flip/transpose(w)) [* lrelu'(h)]: backward-data of a stride-1 'same' conv; with h (the activated tensor
+    the conv consumed) the LeakyReLU backward of the layer below is applied in the kernel's epilogue."""
 
     @staticmethod
-    def forward(ctx, dy, w):
-        ctx.save_for_backward(dy, w)
-        return conv_fwd_raw(dy, w, None, flip=True)
+    def forward(ctx, dy, w, h=None):
+        ctx.save_for_backward(dy, w, h)
+        return conv_fwd_raw(dy, w, None, flip=True, out_mask=h)
 
     @staticmethod
     def backward(ctx, g):
-        dy, w = ctx.saved_tensors
+        dy, w, h = ctx.saved_tensors
         g = _c(g)
+        if h is not None:
+            g = LReLUMaskMul.apply(g, h)     # second order only (the gradient penalty's double backward): a pass of its own
         ddy = Conv.apply(g, w, None, False) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(dy, g, w) if ctx.needs_input_grad[1] else None
-        return ddy, dw
+        return ddy, dw, None
 
 
 class ConvBwdWeight(Function):

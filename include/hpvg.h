@@ -45,9 +45,12 @@ int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* 
  * and are finished in fixed order).  Without it the same kernel runs one workgroup per tile: slower on grids of 1-5
  * tiles per CU slot, results equal up to fp32 summation order. */
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT);
+/* out_mask (optional, shaped like y): y *= (out_mask > 0 ? 1 : 0.2) in the epilogue - leaky_relu_backward
+ * (networks_3d.py:21) of the activation BELOW, fused into the backward-data conv of the layer that consumed it (the
+ * conv's output is the gradient w.r.t. that activation; out_mask = the activated tensor, i.e. this layer's saved input). */
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
-                      int in_lrelu, float* y, int out_lrelu, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
-                      int W, int KT, void* stream);
+                      int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
+                      int Cout, int T, int H, int W, int KT, void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
 /* dW (natural layout) of the conv above: aten::convolution_backward weight half, reached from
  * total_loss.backward() / errD_total.backward() (train_video.py:182,200). accumulate!=0: dw += result. */

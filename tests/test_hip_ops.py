@@ -78,7 +78,7 @@ def test_conv_stream_k_schedules_and_plain_launch(ops, B, Cin, Cout, sp):
     assert (hplib.call("hpvg_conv_fwd_ws_bytes", Bq, Cin, Cout, T, H, W, KT) > 0) == (Cout > 4)  # narrow outputs: direct kernel
     wp = ops.pack_weight(wd, False)
     y_pl = torch.full_like(y_sk, float("nan"))
-    hplib.call("hpvg_conv_fwd_f32", hplib.ptr(xd), hplib.ptr(wp), hplib.ptr(bd), None, None, 0, hplib.ptr(y_pl), 0, None,
+    hplib.call("hpvg_conv_fwd_f32", hplib.ptr(xd), hplib.ptr(wp), hplib.ptr(bd), None, None, 0, hplib.ptr(y_pl), 0, None, None,
                ctypes.c_size_t(0), Bq, Cin, Cout, T, H, W, KT, hplib.stream())
     assert_close(y_pl, want, RTOL, "conv.plain")
     assert_close(y_pl, y_sk, 1e-5, "conv.plain-vs-streamk")
@@ -119,6 +119,60 @@ def test_conv_double_backward_closed_set(ops):
     got = torch.autograd.grad(lossd, [xd, wd, gyd])
     for g, r, n in zip(got, want, ("d/dx", "d/dw", "d/dgy")):
         assert_close(g, r, RTOL, "double." + n)
+
+
+@pytest.mark.parametrize("shape,chans", [((2, 3, 3, 6, 7), (8, 12, 1)), ((1, 3, 9, 11), (64, 64, 3)), ((2, 5, 4, 18, 33), (64, 70, 64))])
+def test_activated_conv_chain_with_consumer_side_masks(ops, shape, chans):
+    """A chain of conv + LeakyReLU layers (the critic / encoder pattern) whose LeakyReLU backward is applied by the CONSUMER
+    conv's backward-data epilogue (ops.Conv in_act / mask_by_consumer, kernel out_mask): first-order gradients and the
+    gradient-penalty style double backward against the oracle's plain autograd over the same chain; also covers the
+    stream-K fix-up path and the narrow-output kernel (Cout <= 4)."""
+    nd = len(shape) - 2
+    x = _rand(*shape, seed=60).requires_grad_(True)
+    cin = shape[1]
+    ws, bs = [], []
+    for i, co in enumerate(chans):
+        ws.append(_rand(co, cin, *([3] * nd), seed=61 + i, scale=0.3).requires_grad_(True))
+        bs.append(_rand(co, seed=71 + i).requires_grad_(True))
+        cin = co
+
+    def chain_ref(x):
+        h = x
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            h = O.conv(h, w, b)
+            if i < len(ws) - 1:
+                h = O.leaky_relu(h)
+        return h
+    y = chain_ref(x)
+    gy = _rand(*y.shape, seed=80)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    pen = ((gx.norm(2, dim=1) - 1) ** 2).mean()
+    want2 = torch.autograd.grad(pen, ws, retain_graph=True)
+    want1 = torch.autograd.grad(y, [x] + ws + bs, gy)
+
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd = [w.detach().to(DEV).requires_grad_(True) for w in ws]
+    bd = [b.detach().to(DEV).requires_grad_(True) for b in bs]
+
+    def chain_hip(x):
+        h = x
+        n = len(wd)
+        for i, (w, b) in enumerate(zip(wd, bd)):
+            h = ops.Conv.apply(h, w, b, i < n - 1, i > 0, i < n - 1)
+        return h
+    yd = chain_hip(xd)
+    assert_close(yd, y, RTOL, "chain.y")
+    got1 = torch.autograd.grad(yd, [xd] + wd + bd, gy.to(DEV), retain_graph=True)
+    for g, r, n in zip(got1, want1, ["dx"] + ["dw%d" % i for i in range(len(ws))] + ["db%d" % i for i in range(len(bs))]):
+        assert_close(g, r, RTOL, "chain." + n, atol=1e-6)
+    with ops.inputs_only():
+        (gxd,) = torch.autograd.grad(yd, xd, gy.to(DEV), create_graph=True)
+    assert_close(gxd, gx, RTOL, "chain.gx")
+    pend = ops.GradPenalty.apply(gxd, 1.0)
+    assert_close(pend, pen, RTOL, "chain.penalty")
+    got2 = torch.autograd.grad(pend, wd)
+    for g, r, i in zip(got2, want2, range(len(ws))):
+        assert_close(g, r, RTOL, "chain.double.dw%d" % i, atol=1e-7)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 3, 5, 7), (2, 64, 4, 18, 33), (1, 16, 37, 41), (2, 64, 1, 1, 3)])
