@@ -144,14 +144,14 @@ __device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int
 }
 
 // Stage channel chunk `ch` (CC channels x KT time planes) of the tile of sample b / output plane t into xs.
-template <int CC, int KT>
+template <int CC, int KT, bool PRO>
 __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs, const StageSlots& sl, int ch, bool first_chunk,
                                                  int b, int t, int tid, int wave) {
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const long HW = (long)a.H * a.W;
   const int PL = a.PL;
-  if (a.in_scale == nullptr) {
+  if constexpr (!PRO) {
     // LDS-DMA staging with as little VALU work as possible (a co-resident wave with MFMAs queued keeps the SIMD's
     // VALU port busy, which stretched a select-per-load version of this loop from 2.4 to 15-20 us per chunk): the
     // per-lane byte offsets are tile constants, the plane base is scalar, out-of-image lanes are switched off by
@@ -224,8 +224,23 @@ __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs
   }
 }
 
-template <int CC, int KT, int MB, int NB>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) {
+// Co-resident workgroups per CU.  Default: two (256 VGPRs each).  Development build -DHPVG_CONV_WGS4: instances with at
+// most 4 accumulator tiles per wave (64 accumulator registers) are compiled for FOUR per CU (<= 128 VGPRs, LDS <= 38 KB)
+// - more workgroups staging while others own the matrix pipe (tools/ab_conv_wgs.py: the A/B).
+#ifdef HPVG_CONV_WGS4
+#define HPVG_CONV_WGS(MB, NB) ((MB) * (NB) <= 4 ? 4 : 2)
+#else
+#define HPVG_CONV_WGS(MB, NB) 2
+#endif
+
+// VAR selects what is compiled around the MFMA loop, so that the plain instance - every forward conv and most backward-data
+// convs of the path - carries none of it (a run-time `if (a.mask)` in the epilogue alone cost the plain launches +1.6 % at
+// stage 9 through register allocation): 0 = plain, 1 = out_mask epilogue (leaky_relu_backward of the layer below),
+// 2 = the producer's BatchNorm-apply (+ LeakyReLU) fused into the staging (register path instead of LDS-DMA).
+constexpr int VAR_PLAIN = 0, VAR_MASK = 1, VAR_PRO = 2;
+
+template <int CC, int KT, int MB, int NB, int VAR>
+__global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(const ConvFwdArgs a) {
   constexpr int CP = CC / 2;
   constexpr int TAPS = KT * 9;
   typedef typename AVecT<CP>::type AVec;
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
       // write hazard the compiler cannot count across the loop's back edge costs an s_waitcnt vmcnt(0) per DMA, i.e.
       // serialises all 72 loads of the chunk (measured: 1.98 -> 2.22 ms at stage 9).
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      conv_stage_chunk<CC, KT>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
+      conv_stage_chunk<CC, KT, VAR == VAR_PRO>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
       HPVG_PH(0)
       __syncthreads();
       HPVG_PH(1)
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvFwdArgs a) 
             float val = acc[m][i][e] + bias_r[m][e];
             if (a.out_lrelu) val = hpvg_lrelu(val);
             const long oi = ((long)b * a.Cout + co) * a.T * HW + sp;
-            if (a.mask) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+            if constexpr (VAR == VAR_MASK) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
             a.y[oi] = val;
           }
         }
@@ -653,6 +668,7 @@ struct Plan {
 };
 
 constexpr long CONV_SLOTS = 2L * HPVG_NUM_CU;  // co-resident workgroups: two per CU (256 VGPRs each, LDS <= 80 KB)
+inline long conv_slots(int MB, int NB) { return (long)HPVG_CONV_WGS(MB, NB) * HPVG_NUM_CU; }
 
 // Tile planner.  streamk = true: the launch is S = min(items, 512) persistent workgroups that share the (tile, chunk)
 // items evenly (needs the partial-slab workspace).  streamk = false: one workgroup per tile, dealt out by the
@@ -737,7 +753,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
         if (plload > NJMAX * 256) continue;
         const int PL = Lmax + 2 * RS + 2;  // lanes past L still read (junk) operands inside the buffer
         const size_t lds = (size_t)CC * KT * PL * sizeof(float);
-        if (lds > 80 * 1024) continue;
+        if (lds > (HPVG_CONV_WGS(MB, NB) == 4 ? 38 : 80) * 1024) continue;
         const long ntl = (long)B * T * nrange * ntw * gridy;
         const double stage_us = 0.0065 * plload;
         double cost;
@@ -749,7 +765,8 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
           // tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block, written by
           // the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth)
           const long items_tot = ntl * nchunk;
-          const long S = items_tot < CONV_SLOTS ? items_tot : CONV_SLOTS;
+          const long slots = conv_slots(MB, NB);
+          const long S = items_tot < slots ? items_tot : slots;
           const long ndp = ntl / S;
           const long rem = (ntl - ndp * S) * nchunk;
           const double items = (double)(ndp * nchunk) + (double)((rem + S - 1) / S);
@@ -813,17 +830,19 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool strea
 // Launch of S workgroups.  The dynamic LDS request is padded to 56 KB so that a third workgroup never fits on a CU:
 // the persistent grid is sized for exactly two.
 constexpr size_t CONV_MIN_LDS = 56 * 1024;
-template <int CC, int KT, int MB, int NB>
-int launch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+template <int CC, int KT, int MB, int NB, int VAR>
+int launch_conv_var(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_kernel<CC, KT, MB, NB>;
+  auto kern = conv_mfma_kernel<CC, KT, MB, NB, VAR>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       (void)hipGetLastError();
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(S), dim3(256), p.lds < CONV_MIN_LDS ? CONV_MIN_LDS : p.lds, s, a);
+  // (four per CU: pad to 33 KB so that a fifth never fits)
+  const size_t min_lds = HPVG_CONV_WGS(MB, NB) == 4 ? (size_t)33 * 1024 : CONV_MIN_LDS;
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), p.lds < min_lds ? min_lds : p.lds, s, a);
   int rc = hpvg_launch_status();
   if (rc != HPVG_OK) return rc;
   const int nsk = a.ntl - a.skbase;
@@ -832,6 +851,13 @@ int launch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
     rc = hpvg_launch_status();
   }
   return rc;
+}
+
+template <int CC, int KT, int MB, int NB>
+int launch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+  if (a.in_scale) return launch_conv_var<CC, KT, MB, NB, VAR_PRO>(a, p, S, s);
+  if (a.mask) return launch_conv_var<CC, KT, MB, NB, VAR_MASK>(a, p, S, s);
+  return launch_conv_var<CC, KT, MB, NB, VAR_PLAIN>(a, p, S, s);
 }
 
 template <int CC, int KT>
@@ -872,9 +898,10 @@ int launch_conv_narrow(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
 }
 
 // stream-K grid for a plan: all co-resident slots, or one workgroup per item when there are fewer items than slots
-inline int conv_sk_grid(int ntl, int nchunk) {
+inline int conv_sk_grid(int ntl, int nchunk, const Plan& p) {
   const long items = (long)ntl * nchunk;
-  return (int)(items < CONV_SLOTS ? items : CONV_SLOTS);
+  const long slots = conv_slots(p.MB, p.NB);
+  return (int)(items < slots ? items : slots);
 }
 inline size_t conv_sk_ws_bytes(const Plan& p, int S) { return (size_t)S * 2 * p.MB * p.NB * 16 * 256 * sizeof(float); }
 
@@ -947,6 +974,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return HPVG_ERR_ARG;
+  if (in_scale && out_mask && !conv_is_narrow(Cin, Cout)) return HPVG_ERR_UNSUPPORTED;  // no caller combines prologue and mask
   // development knob: HPVG_CONV_SK=0 forces the one-workgroup-per-tile schedule
   static const bool sk_off = [] { const char* e = getenv("HPVG_CONV_SK"); return e && atoi(e) == 0; }();
   const int CC = conv_cc(Cin);
@@ -955,7 +983,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk);
   if (p.L == 0) return HPVG_ERR_UNSUPPORTED;
   int ntl = B * T * p.nrange * p.ntw * p.gridy;
-  if (streamk && ws_bytes < conv_sk_ws_bytes(p, conv_sk_grid(ntl, nchunk))) {
+  if (streamk && ws_bytes < conv_sk_ws_bytes(p, conv_sk_grid(ntl, nchunk, p))) {
     streamk = false;
     p = plan_conv(B, Cin, Cout, T, H, W, KT, false);
     ntl = B * T * p.nrange * p.ntw * p.gridy;
@@ -974,7 +1002,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
     a.ndp = 1; a.skbase = ntl; a.skpart = nullptr;
     return KT == 3 ? launch_conv_narrow<3>(a, p, (hipStream_t)stream) : launch_conv_narrow<1>(a, p, (hipStream_t)stream);
   }
-  const int S = streamk ? conv_sk_grid(ntl, nchunk) : ntl;  // S = ntl: one data-parallel round, no stream-K part
+  const int S = streamk ? conv_sk_grid(ntl, nchunk, p) : ntl;  // S = ntl: one data-parallel round, no stream-K part
   a.ndp = ntl / S;
   a.skbase = a.ndp * S;
   a.skpart = (float*)ws;
@@ -989,7 +1017,7 @@ size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int
   if (conv_is_narrow(Cin, Cout)) return 0;
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
   if (p.L == 0) return 0;
-  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nrange * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin))));
+  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nrange * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin)), p));
 }
 
 // Debug/introspection: the tile plan of the stream-K launch (for tests and DESIGN.md tables).
