@@ -380,6 +380,107 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_fused_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------ BatchNorm + LeakyReLU, SECOND order
+// The gradient penalty of a critic with BatchNorm (WDiscriminatorBaselines, networks_3d.py:184-210; modules/utils.py:14-18)
+// differentiates the first-order backward  dr = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),  dz = dh*lrelu'(z),
+// once more.  With G = dL/d(dr), N elements per channel and per-channel sums  Sd = sum dz, Sdx = sum dz*xhat, SG = sum G,
+// SGx = sum G*xhat, SdG = sum dz*G  (torch: batchnorm_double_backward, ggG = ggB = none; lrelu'' = 0):
+//   dL/d(dh)  = lrelu'(z) * gamma*invstd * (G - SG/N - xhat*SGx/N)
+//   dL/d(r)   = gamma*invstd^2 * ( xhat*(SG*Sd/N - SdG + 3*Sdx*SGx/N)/N + (SGx/N)*(Sd/N - dz) + (Sdx/N)*(SG/N - G) )
+//   dL/dgamma = invstd * (SdG - Sd*SG/N - Sdx*SGx/N)
+template <int V>
+__global__ __launch_bounds__(256) void bn_lrelu_bwd2_reduce_kernel(const float* __restrict__ dh, const float* __restrict__ G,
+                                                                    const float* __restrict__ r, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int B, int C, long S, int nsplit,
+                                                                    int lrelu, double* __restrict__ part) {
+  typedef typename HpvgVec<V>::type Vec;
+  __shared__ double sh[4];
+  const int c = blockIdx.y, k = blockIdx.x;
+  const long SV = S / V;
+  const long chunk = (SV + nsplit - 1) / nsplit;
+  const long lo = (long)k * chunk, hi = (lo + chunk < SV) ? lo + chunk : SV;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < B; ++b) {
+    const Vec* dp = reinterpret_cast<const Vec*>(dh + ((long)b * C + c) * S);
+    const Vec* gp = reinterpret_cast<const Vec*>(G + ((long)b * C + c) * S);
+    const Vec* rp = reinterpret_cast<const Vec*>(r + ((long)b * C + c) * S);
+    float f[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+      const Vec rv4 = rp[i], dz4 = dp[i], g4 = gp[i];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float rv = hpvg_vget<V>(rv4, e);
+        float dz = hpvg_vget<V>(dz4, e);
+        const float g = hpvg_vget<V>(g4, e);
+        if (lrelu && !(rv * sc + sf > 0.f)) dz *= HPVG_LRELU_SLOPE;
+        const float xh = (rv - mu) * is;
+        f[0] += dz; f[1] += dz * xh; f[2] += g; f[3] += g * xh; f[4] += dz * g;
+      }
+      if (++cnt == 32 / V) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { a[q] += f[q]; f[q] = 0.f; }
+        cnt = 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) a[q] += f[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const double t = hpvg_block_sum_d(a[q], sh);
+    if (threadIdx.x == 0) part[((long)c * nsplit + k) * 5 + q] = t;
+  }
+}
+
+// per channel: the five sums -> constants of the apply pass (Sd/N, Sdx/N, SG/N, SGx/N, all_sub/N) and dgamma
+__global__ void bn_bwd2_finalize_kernel(const double* __restrict__ part, int nsplit, int C, double count,
+                                        const float* __restrict__ invstd, float* __restrict__ consts, float* __restrict__ dgamma,
+                                        int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < nsplit; ++k)
+    for (int q = 0; q < 5; ++q) t[q] += part[((long)c * nsplit + k) * 5 + q];
+  const double Sd = t[0], Sdx = t[1], SG = t[2], SGx = t[3], SdG = t[4];
+  const double inv = 1.0 / count;
+  consts[5 * c + 0] = (float)(Sd * inv);
+  consts[5 * c + 1] = (float)(Sdx * inv);
+  consts[5 * c + 2] = (float)(SG * inv);
+  consts[5 * c + 3] = (float)(SGx * inv);
+  consts[5 * c + 4] = (float)((SG * Sd * inv - SdG + 3.0 * Sdx * SGx * inv) * inv);
+  if (dgamma) {
+    const float v = (float)((double)invstd[c] * (SdG - Sd * SG * inv - Sdx * SGx * inv));
+    dgamma[c] = accumulate ? dgamma[c] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_lrelu_bwd2_apply_kernel(const float* __restrict__ dh, const float* __restrict__ G,
+                                                                   const float* __restrict__ r, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ consts,
+                                                                   float* __restrict__ g_dh, float* __restrict__ g_r, int C, long S,
+                                                                   int lrelu) {
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sf = shift[c];
+  const float mSd = consts[5 * c], mSdx = consts[5 * c + 1], mSG = consts[5 * c + 2], mSGx = consts[5 * c + 3], asub = consts[5 * c + 4];
+  const float* dp = dh + (long)bc * S;
+  const float* gp = G + (long)bc * S;
+  const float* rp = r + (long)bc * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    const float rv = rp[i], g = gp[i];
+    float dz = dp[i];
+    const float m = (lrelu && !(rv * sc + sf > 0.f)) ? HPVG_LRELU_SLOPE : 1.f;
+    dz *= m;
+    const float xh = (rv - mu) * is;
+    if (g_dh) g_dh[(long)bc * S + i] = m * sc * (g - mSG - xh * mSGx);
+    if (g_r) g_r[(long)bc * S + i] = sc * is * (xh * asub + mSGx * (mSd - dz) + mSdx * (mSG - g));
+  }
+}
+
 // ------------------------------------------------------------------ pointwise
 // out = dy * (h > 0 ? 1 : 0.2)    (leaky_relu_backward on the in-place activated tensor)
 __global__ __launch_bounds__(256) void lrelu_mask_mul_kernel(const float* __restrict__ dy, const float* __restrict__ h,
@@ -1085,6 +1186,35 @@ int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, cons
   hipLaunchKernelGGL(bn_lrelu_bwd_apply_fused_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, r, mean, invstd, scale, shift,
                      (const double*)part, ns, dgamma, dbeta, accumulate, dr, C, S, (float)(1.0 / ((double)Bg * (double)S)), lrelu, Bg,
                      groups, gstride);
+  return hpvg_launch_status();
+}
+
+// second-order backward of h = LeakyReLU_opt(BN_train(r)) (see bn_lrelu_bwd2_reduce_kernel): g = dL/d(dr) of the first-order
+// backward; outputs (each optional): g_dh = dL/d(dh), g_r = dL/d(r), g_gamma = dL/d(gamma) (+= when accumulate).
+size_t hpvg_bn_bwd2_ws_bytes(int C) { return (size_t)C * 64 * 5 * sizeof(double) + (size_t)C * 5 * sizeof(float); }
+int hpvg_bn_act_bwd2_f32(const float* dh, const float* g, const float* r, const float* mean, const float* invstd, const float* scale,
+                         const float* shift, int lrelu, float* g_dh, float* g_r, float* g_gamma, int accumulate, void* ws,
+                         size_t ws_bytes, int B, int C, long S, void* stream) {
+  if (!dh || !g || !r || !mean || !invstd || !scale || !shift || !ws || B < 1 || C < 1 || S < 1) return HPVG_ERR_ARG;
+  if (ws_bytes < hpvg_bn_bwd2_ws_bytes(C)) return HPVG_ERR_WORKSPACE;
+  const int ns = bn_nsplit(B, C, S);
+  hipStream_t s = (hipStream_t)stream;
+  double* part = (double*)ws;
+  float* consts = (float*)((char*)ws + (size_t)C * 64 * 5 * sizeof(double));
+  int vw = hpvg_vec_width(dh, S);
+  if (hpvg_vec_width(g, S) < vw) vw = hpvg_vec_width(g, S);
+  if (hpvg_vec_width(r, S) < vw) vw = hpvg_vec_width(r, S);
+  if (vw == 4) hipLaunchKernelGGL(bn_lrelu_bwd2_reduce_kernel<4>, dim3(ns, C), dim3(256), 0, s, dh, g, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
+  else if (vw == 2) hipLaunchKernelGGL(bn_lrelu_bwd2_reduce_kernel<2>, dim3(ns, C), dim3(256), 0, s, dh, g, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
+  else hipLaunchKernelGGL(bn_lrelu_bwd2_reduce_kernel<1>, dim3(ns, C), dim3(256), 0, s, dh, g, r, mean, invstd, scale, shift, B, C, S, ns, lrelu, part);
+  hipLaunchKernelGGL(bn_bwd2_finalize_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, ns, C, (double)B * (double)S,
+                     invstd, consts, g_gamma, accumulate);
+  if (g_dh || g_r) {
+    int nbx = hpvg_cdiv(S, 256 * 4);
+    if (nbx > 1024) nbx = 1024;
+    hipLaunchKernelGGL(bn_lrelu_bwd2_apply_kernel, dim3(nbx, B * C), dim3(256), 0, s, dh, g, r, mean, invstd, scale, shift,
+                       (const float*)consts, g_dh, g_r, C, S, lrelu);
+  }
   return hpvg_launch_status();
 }
 

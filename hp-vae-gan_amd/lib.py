@@ -43,6 +43,8 @@ _SIGS = {
     "hpvg_affine_act_f32": [P, P, P, P, I, I, I, L, P],
     "hpvg_bn_train_fwd_f32": [P, P, P, P, P, F, F, P, P, P, P, P, I, I, P, Z, I, I, L, P],
     "hpvg_bn_act_bwd_f32": [P, P, P, P, P, P, I, I, P, P, P, I, P, Z, I, I, L, P],
+    "hpvg_bn_bwd2_ws_bytes": [I],
+    "hpvg_bn_act_bwd2_f32": [P, P, P, P, P, P, P, I, P, P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_sums_f32": [P, P, P, Z, I, I, L, P],
     "hpvg_bn_finalize_f32": [P, D, P, P, P, P, F, F, P, P, P, P, I, P],
     "hpvg_bn_act_bwd_sums_f32": [P, P, P, P, P, P, I, P, P, Z, I, I, L, P],
@@ -79,7 +81,7 @@ _SIGS = {
     "hpvg_counter_inc_i32": [P, P],
     "hpvg_graph_node_census": [P, P, I],
 }
-_SIZE_FUNCS = {"hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 
 
 def header_symbols():

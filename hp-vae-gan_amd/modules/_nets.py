@@ -508,41 +508,22 @@ class GeneratorCSG(nn.Module):
         return ops.TanhRes.apply(self.tail(self._zero_pad(x_prev_out, 1)), None)
 
 
-class _ConvNormActTwice(nn.Module):
-    """Conv -> BatchNorm3d (batch statistics) -> LeakyReLU(0.2) for a critic whose gradient penalty differentiates the
-    block TWICE: the conv is the gfx950 kernel family (closed under differentiation, ops.Conv), BatchNorm and LeakyReLU
-    are torch's own double-differentiable ops (ops.BNAct is first-order only).  Same child names / state-dict keys as
-    ConvBlock (conv.*, norm.*)."""
-
-    def __init__(self, in_channel, out_channel, ker_size, padding, bn=True):
-        super().__init__()
-        self.conv = Conv(3, in_channel, out_channel, ker_size, padding, 1)
-        if bn:
-            self.norm = nn.BatchNorm3d(out_channel)
-        self.has_bn = bn
-
-    def forward(self, x):
-        y = self.conv(x)
-        if self.has_bn:
-            y = self.norm(y)
-        return torch.nn.functional.leaky_relu(y, 0.2)
-
-
 class WDiscriminatorBaselines(nn.Module):
     """The baselines' own critic (reference: networks_3d.py:184-210; `--discriminator WDiscriminatorBaselines`): input
     zero-padded by num_layer + 2 voxels per side, head conv + LeakyReLU (no norm), num_layer x [conv + BatchNorm +
-    LeakyReLU], tail conv, weights_init.  Convolutions run on the gfx950 kernels; BatchNorm / LeakyReLU go through torch
-    (see _ConvNormActTwice): this is the one place on the path where the WGAN-GP needs BatchNorm's second derivative."""
+    LeakyReLU], tail conv, weights_init.  The one place on the path where the WGAN-GP needs BatchNorm's SECOND derivative:
+    ops.BNAct's backward runs as the differentiable ops.BNActBwd while the penalty's graph is recorded, and its double
+    backward is the gfx950 kernel pair hpvg_bn_act_bwd2_f32 - every arithmetic op of this critic is a kernel of libhpvg."""
 
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
         N = int(opt.nfc)
         self.pad = opt.num_layer + 2
-        self.head = _ConvNormActTwice(opt.nc_im, N, opt.ker_size, opt.padd_size, bn=False)
+        self.head = ConvBlock(3, opt.nc_im, N, opt.ker_size, opt.padd_size, 1, bn=False, act='lrelu')
         self.body = nn.Sequential()
         for i in range(opt.num_layer):
-            self.body.add_module('block%d' % i, _ConvNormActTwice(N, N, opt.ker_size, opt.padd_size, bn=True))
+            self.body.add_module('block%d' % i, ConvBlock(3, N, N, opt.ker_size, opt.padd_size, 1, bn=True, act='lrelu'))
         self.tail = Conv(3, N, 1, opt.ker_size, opt.padd_size, 1)
         self.apply(weights_init)
 

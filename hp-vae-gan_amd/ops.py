@@ -401,10 +401,16 @@ class BNAct(Function):
         return h
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dh):
         r, stats, gamma, beta = ctx.saved_tensors
         dh = _c(dh)
+        if torch.is_grad_enabled():
+            # a graph is being recorded over this backward (create_graph=True: the gradient penalty of a critic that contains
+            # BatchNorm, WDiscriminatorBaselines): run it as a differentiable op of its own
+            if ctx.groups != 1:
+                raise NotImplementedError("second-order BatchNorm is implemented for groups == 1")
+            dr, dg, db = BNActBwd.apply(dh, r, gamma, stats, ctx.lrelu)
+            return dr, dg, db, None, None, None, None, None, None
         B, C, T, H, W = geom(r)
         S = T * H * W
         dev = r.device
@@ -422,6 +428,48 @@ class BNAct(Function):
         if direct:
             return dr, None, None, None, None, None, None, None, None
         return dr, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+class BNActBwd(Function):
+    """(dr, dgamma, dbeta) = backward of BNAct as a DIFFERENTIABLE op: what BNAct.backward runs while a graph is recorded
+    over it.  Its own backward is the second-order BatchNorm kernel pair (hpvg_bn_act_bwd2_f32): gradients w.r.t. dh, r and
+    gamma of <dr, g>; dgamma / dbeta are not differentiated on the path (the penalty differentiates input gradients only)."""
+
+    @staticmethod
+    def forward(ctx, dh, r, gamma, stats, lrelu):
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        dr = torch.empty_like(r)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        ws = workspace(call("hpvg_bn_ws_bytes", C), dev)
+        st = stats[0]
+        call("hpvg_bn_act_bwd_f32", ptr(dh), ptr(r), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), 1 if lrelu else 0, 1,
+             ptr(dr), ptr(dgb[0]), ptr(dgb[1]), 0, ptr(ws), ctypes.c_size_t(ws.numel()), B, C, ctypes.c_long(S), stream())
+        ctx.save_for_backward(dh, r, gamma, stats)
+        ctx.lrelu = lrelu
+        dg, db = dgb[0], dgb[1]
+        ctx.mark_non_differentiable(dg, db)
+        return dr, dg, db
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _g_dgamma, _g_dbeta):
+        dh, r, gamma, stats = ctx.saved_tensors
+        g = _c(g)
+        B, C, T, H, W = geom(r)
+        S = T * H * W
+        dev = r.device
+        g_dh = torch.empty_like(r) if ctx.needs_input_grad[0] else None
+        g_r = torch.empty_like(r) if ctx.needs_input_grad[1] else None
+        slot = grad_slot(gamma) if ctx.needs_input_grad[2] else None
+        g_gamma = slot if slot is not None else (torch.empty(C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None)
+        ws = workspace(call("hpvg_bn_bwd2_ws_bytes", C), dev)
+        st = stats[0]
+        call("hpvg_bn_act_bwd2_f32", ptr(dh), ptr(g), ptr(r), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), 1 if ctx.lrelu else 0,
+             ptr(g_dh), ptr(g_r), ptr(g_gamma), 1 if slot is not None else 0, ptr(ws), ctypes.c_size_t(ws.numel()), B, C,
+             ctypes.c_long(S), stream())
+        return g_dh, g_r, (None if slot is not None else g_gamma), None, None
 
 
 def concat_batch(parts, like=None):

@@ -85,6 +85,14 @@ int hpvg_affine_act_f32(const float* x, const float* scale, const float* shift, 
 int hpvg_bn_act_bwd_f32(const float* dh, const float* r, const float* mean, const float* invstd, const float* scale,
                         const float* shift, int lrelu, int groups, float* dr, float* dgamma, float* dbeta, int accumulate, void* ws,
                         size_t ws_bytes, int B, int C, long S, void* stream);
+/* SECOND-order backward of the same block: the WGAN-GP of a critic that contains BatchNorm (WDiscriminatorBaselines,
+ * networks_3d.py:184-210; modules/utils.py:14-18) differentiates the first-order backward once more.  g = dL/d(dr);
+ * outputs (each nullable): g_dh = dL/d(dh), g_r = dL/d(r), g_gamma = dL/d(gamma) (+= when accumulate).  torch:
+ * batchnorm_double_backward + leaky_relu_backward (LeakyReLU'' = 0). */
+size_t hpvg_bn_bwd2_ws_bytes(int C);
+int hpvg_bn_act_bwd2_f32(const float* dh, const float* g, const float* r, const float* mean, const float* invstd, const float* scale,
+                         const float* shift, int lrelu, float* g_dh, float* g_r, float* g_gamma, int accumulate, void* ws,
+                         size_t ws_bytes, int B, int C, long S, void* stream);
 /* BatchNorm with the batch split over ranks (one process per GPU): the rank-local per-channel sums are double pairs the
  * caller all-reduces (RCCL) between the two halves; statistics, running buffers and dr then follow from the global sums.
  * Same arithmetic as the single-GPU entry points above (which are sums + finalize / sums + apply in one call). */

@@ -199,6 +199,37 @@ def test_bn_act(ops, shape):
     assert_close(dbd, db, RTOL, "bn.dbeta")
 
 
+@pytest.mark.parametrize("shape,lrelu", [((2, 8, 3, 5, 7), True), ((2, 64, 4, 18, 33), True), ((1, 16, 37, 41), False), ((3, 5, 2, 3, 4), True)])
+def test_bn_act_double_backward(ops, shape, lrelu):
+    """Second-order BatchNorm (+ LeakyReLU): what the gradient penalty of the baselines' BatchNorm critic differentiates
+    (networks_3d.py:184-210, modules/utils.py:14-18).  d/dr, d/dgamma and d/d(dh) of a functional of the first-order input
+    gradient, against torch autograd over the oracle's written-out BatchNorm."""
+    C = shape[1]
+    r = (_rand(*shape, seed=120) * 1.3 + 0.2).requires_grad_(True)
+    gamma = (_rand(C, seed=121).abs() + 0.5).requires_grad_(True)
+    beta = _rand(C, seed=122).requires_grad_(True)
+    gh = _rand(*shape, seed=123).requires_grad_(True)
+    wgt = _rand(*shape, seed=124)
+
+    def fwd(r, gamma, beta):
+        y = O.batch_norm_train(r, gamma, beta, torch.zeros(C), torch.ones(C))
+        return O.leaky_relu(y) if lrelu else y
+    h = fwd(r, gamma, beta)
+    (dr,) = torch.autograd.grad(h, r, gh, create_graph=True)
+    loss = (dr * wgt).sum() + 0.5 * (dr ** 2).sum()
+    want = torch.autograd.grad(loss, [r, gamma, gh])
+
+    rd, gd, bd, ghd = (t.detach().to(DEV).requires_grad_(True) for t in (r, gamma, beta, gh))
+    hd = ops.BNAct.apply(rd, gd, bd, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), 0.1, 1e-5, lrelu)
+    assert_close(hd, h, RTOL, "bn2.h")
+    (drd,) = torch.autograd.grad(hd, rd, ghd, create_graph=True)
+    assert_close(drd, dr, RTOL, "bn2.dr")
+    lossd = (drd * wgt.to(DEV)).sum() + 0.5 * (drd ** 2).sum()
+    got = torch.autograd.grad(lossd, [rd, gd, ghd])
+    for g, w_, n in zip(got, want, ("d/dr", "d/dgamma", "d/d(dh)")):
+        assert_close(g, w_, RTOL, "bn2." + n, atol=1e-6)
+
+
 def test_bn_act_batch_split_equals_whole_batch(ops):
     """Multi-GPU BatchNorm: two 'ranks' hold one sample each; with the per-channel sums exchanged (here: added by hand, as
     the all-reduce would) outputs, running statistics, dr and the summed parameter gradients equal BNAct on the batch."""
