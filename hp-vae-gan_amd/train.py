@@ -81,6 +81,9 @@ class StageTrainer:
         self.iteration = 0
         self.clip_info = torch.zeros(2, dtype=torch.float32, device=opt.device)
         self.last = {}
+        # test hook: callable(trainer) run right after the discriminator's optimizer step (the parity tests put the reference's
+        # post-step critic in place there, so that the generator step is judged from an identical state: see tests/helpers.py)
+        self.after_d_step = None
 
     def calibrate_noise_amp(self, real, real_zero):
         """Iteration-0 noise amplitude (train_video.py:131-145)."""
@@ -191,6 +194,8 @@ class StageTrainer:
             if getattr(opt, 'record_grads', False):
                 out['gradD_flat'] = self.arenaD.grad.clone()
             self.optimizerD.step()
+            if self.after_d_step is not None:
+                self.after_d_step(self)
 
             rec_loss = mse_loss(generated, real)
             # D's own weight gradients of this pass are discarded by the reference (D.zero_grad() next iteration);
@@ -276,6 +281,7 @@ class BaselineStageTrainer:
         self.arenaG = hp_optim.ParamArena(netG)
         self.optimizerG = hp_optim.FlatAdam(self.arenaG, groups, betas=(opt.beta1, 0.999))
         self.iteration = 0
+        self.after_d_step = None   # test hook: callable(trainer, j) after the j-th discriminator update (see StageTrainer)
 
     def step(self, real, noise_init=None, alphas=None):
         opt, netG, netD = self.opt, self.netG, self.netD
@@ -307,6 +313,8 @@ class BaselineStageTrainer:
             if getattr(opt, 'record_grads', False):
                 out['gradD_flat'] = self.arenaD.grad.clone()
             self.optimizerD.step()
+            if self.after_d_step is not None:
+                self.after_d_step(self, j)
         for p in netD.parameters():
             p.requires_grad_(False)
         errG = wgan_mean(netD(fake), -1.0) * opt.disc_loss_weight

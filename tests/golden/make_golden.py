@@ -118,6 +118,22 @@ SEED_OVERRIDE = [None]   # main(): re-run a job on exactly the seed its first ru
 # implementations after a few dozen layers).  The spread between the plain and the perturbed run is how much the reference
 # itself moves when its rounding is disturbed - after an optimizer step that includes Adam's sign flips of ~0 gradients.
 INPUT_EPS = [0.0]
+# main(): relative size (of a tensor's largest gradient) of Gaussian noise added to every gradient just before its optimizer
+# step in a re-run.  Adam's first step is lr * g / (|g| + 1e-8) ~ lr * sign(g): any two fp32 implementations disagree on the
+# sign of gradients smaller than their rounding difference (1e-7 ... 1e-4 of the tensor's scale after 10^5-term sums), each
+# such weight then lands 2 lr apart, and everything computed AFTER the step (the G-step critic term and the generator's
+# gradients in a GAN stage) moves with it.  This run measures that movement in the reference itself.
+GRAD_NOISE = [0.0]
+
+
+def noisy_grads(params, seed):
+    if not GRAD_NOISE[0]:
+        return
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in params:
+            if p.grad is not None and p.grad.numel():
+                p.grad.add_(GRAD_NOISE[0] * float(p.grad.abs().max()) * torch.randn(p.grad.shape, generator=g))
 
 
 def iter_spread(a, b):
@@ -269,6 +285,7 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
                 errD_total = errD_real + errD_fake + gp
                 errD_total.backward()
                 rec_i['gradsD'] = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in D.named_parameters()}
+                noisy_grads(D.parameters(), 7000 + it)
                 optimizerD.step()
                 rec_loss = rec_loss_fn(generated, real)
                 errG = -D(fake).mean() * opt.disc_loss_weight
@@ -280,6 +297,7 @@ def run_stage_steps(images, nets, losses, mutils, opt, dims, scale_idx, n_iters,
             total_loss.backward()
             rec_i['gradsG'] = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in netG.named_parameters()}
             total_norm = torch.nn.utils.clip_grad_norm_(netG.parameters(), opt.grad_clip)
+            noisy_grads(netG.parameters(), 8000 + it)
             optimizerG.step()
         rec_i.update(total_loss=total_loss.detach().clone(), total_norm=total_norm.detach().clone(),
                      generated=generated.detach().clone(), generated_vae=generated_vae.detach().clone(),
@@ -387,6 +405,7 @@ def run_wide_step(images, nets, losses, mutils, opt, dims, scale_idx, threads):
             gp = mutils.calc_gradient_penalty(D, real, fake, opt.lambda_grad, 'cpu')
             (errD_real + errD_fake + gp).backward()
             out['gradsD'] = {n: detfill.summarize(p.grad, 256) for n, p in D.named_parameters()}
+            noisy_grads(D.parameters(), 7000)
             optimizerD.step()
             rec_loss = rec_loss_fn(generated, real)
             errG = -D(fake).mean() * opt.disc_loss_weight
@@ -397,6 +416,7 @@ def run_wide_step(images, nets, losses, mutils, opt, dims, scale_idx, threads):
         total_loss.backward()
         out['gradsG'] = {n: (detfill.summarize(p.grad, 256) if p.grad is not None else None) for n, p in netG.named_parameters()}
         total_norm = torch.nn.utils.clip_grad_norm_(netG.parameters(), opt.grad_clip)
+        noisy_grads(netG.parameters(), 8000)
         optimizerG.step()
     out.update(total_loss=float(total_loss), total_norm=float(total_norm), noise_amps=list(noise_amps), noise_shapes=rec.shapes,
                alpha=DetNoise.ALPHA, generated=detfill.summarize(generated, 4096), generated_vae=detfill.summarize(generated_vae, 4096),
@@ -439,16 +459,21 @@ def wide_fixture(images, nets, losses, mutils, dims, scale_idx):
         pert = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
     finally:
         INPUT_EPS[0] = 0.0
+    GRAD_NOISE[0] = 1e-5
+    try:
+        noisy = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
+    finally:
+        GRAD_NOISE[0] = 0.0
     torch.set_num_threads(1)
     o = opt()
     images.adjust_scales2image(o.img_size, o)
     lr = o.lr_g
-    spread = merge_spread(_spread(one, many), _spread(one, pert))
+    spread = merge_spread(merge_spread(_spread(one, many), _spread(one, pert)), _spread(one, noisy))
     for name in ('G_delta', 'D_delta'):   # fraction of sampled weights whose update differs by more than lr/10 between the runs
         if name in one:
             for k in one[name]:
                 fr = 0.0
-                for other in (many, pert):
+                for other in (many, pert, noisy):
                     d = (one[name][k]['sample'].double() - other[name][k]['sample'].double()).abs()
                     fr = max(fr, float((d > lr / 10).double().mean()))
                 spread[name][k]['frac_lr10'] = fr
@@ -507,6 +532,7 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
                     z_rec = netG(Z_init, noise_amps, mode="rec")
                     rmse = torch.sqrt(F.mse_loss(real, z_rec))
                     noise_amps[-1] = opt.noise_amp_init * rmse.item() / opt.batch_size
+            d_steps = []      # the critic after each of its Dsteps updates
             for j in range(opt.Dsteps):
                 D.zero_grad()
                 errD_real = -D(real).mean()
@@ -519,20 +545,23 @@ def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, genera
                 gp = mutils.calc_gradient_penalty(D, real, fake, opt.lambda_grad, 'cpu')
                 (errD_real + errD_fake + gp).backward()
                 gradsD = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in D.named_parameters()}
+                noisy_grads(D.parameters(), 7000 + 10 * it + j)
                 optimizerD.step()
+                d_steps.append(sd_clone(D))
             errG = -D(fake).mean() * opt.disc_loss_weight
             generated = netG(Z_init, noise_amps, mode="rec")
             rec_loss = opt.alpha * rec_loss_fn(generated, real)
             netG.zero_grad()
             (errG + rec_loss).backward()
             gradsG = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in netG.named_parameters()}
+            noisy_grads(netG.parameters(), 8000 + it)
             for _ in range(opt.Gsteps):
                 optimizerG.step()
         fx['iters'].append({'noise_init': rec.normals[0], 'noises': rec.normals[1:], 'alphas': list(rec.rands),
                             'errD_real': errD_real.detach().clone(), 'errD_fake': errD_fake.detach().clone(),
                             'gradient_penalty': gp.detach().clone(), 'errG': errG.detach().clone(), 'rec_loss': rec_loss.detach().clone(),
                             'fake': fake.detach().clone(), 'generated': generated.detach().clone(), 'gradsD': gradsD, 'gradsG': gradsG,
-                            'noise_amps': list(noise_amps), 'G_after': sd_clone(netG), 'D_after': sd_clone(D)})
+                            'noise_amps': list(noise_amps), 'G_after': sd_clone(netG), 'D_after': sd_clone(D), 'D_steps': d_steps})
     km.close()
     fx['kink_margin'] = km.margin
     fx['seed'] = seed
@@ -735,7 +764,13 @@ def main():
                     fxp = jobs[name]()
                 finally:
                     SEED_OVERRIDE[0], INPUT_EPS[0] = None, 0.0
-                fx['spread'] = [merge_spread(iter_spread(a, b), iter_spread(a, c)) for a, b, c in zip(fx['iters'], fx8['iters'], fxp['iters'])]
+                SEED_OVERRIDE[0], GRAD_NOISE[0] = fx['seed'], 1e-5
+                try:
+                    fxn = jobs[name]()
+                finally:
+                    SEED_OVERRIDE[0], GRAD_NOISE[0] = None, 0.0
+                fx['spread'] = [merge_spread(merge_spread(iter_spread(a, b), iter_spread(a, c)), iter_spread(a, d))
+                                for a, b, c, d in zip(fx['iters'], fx8['iters'], fxp['iters'], fxn['iters'])]
             torch.save(fx, os.path.join(OUT, name))
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

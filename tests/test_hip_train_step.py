@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
                                    "step3d_gan_s3_td2.pt", "step3d_gan_s2_all.pt", "step3d_gan_s7.pt"])
 def test_train_step_matches_reference(fname):
     """Tolerances are measured, not guessed: each quantity gets max(1e-3 relative (north_star), 2 x the spread the reference
-    itself shows for it between its oneDNN, native-ATen and input-perturbed (2^-20) evaluations; fx["spread"]).  Post-step
-    parameters are judged by their UPDATE: frozen parameters must be bit-identical to the initial state, trained ones must
-    make the reference's Adam step (learning rate of their group, bounded by lr) except on the sign-flip fraction."""
+    itself shows for it between its oneDNN, native-ATen, input-perturbed (2^-20) and gradient-noise evaluations;
+    fx["spread"]).  Optimizer steps are judged by their UPDATE: frozen parameters must be bit-identical to the initial state,
+    trained ones must make the reference's Adam step (learning rate of their group, bounded by lr) except on the sign-flip
+    fraction; everything after a step is computed from the reference's post-step state (helpers.run_hip_stage, sync)."""
     from helpers import _bn_fed_bias, compare_step, compare_update
     from hp_vae_gan_amd import train as hp_train
     fx = load_golden(fname)
@@ -54,7 +55,7 @@ def test_train_step_matches_reference(fname):
                 assert_close(sdG[k].float(), v.float(), RTOL, what + ".G_after." + k, atol=max(1e-6, 2 * (spread or {}).get("G_after", {}).get(k, 0.0)))
         prevG = {k: v.clone() for k, v in rec["G_after"].items()}
         if rec["D_after"] is not None:
-            sdD = netD.state_dict()
+            sdD = out["D_hip_after"]          # the critic as OUR optimizer step left it (before the reference's state replaced it)
             dnames = dict(netD.named_parameters())
             for k, v in rec["D_after"].items():
                 if k in dnames:
@@ -128,6 +129,13 @@ def test_baseline_singan_step_matches_reference(fname, generator, critic):
     tr = hp_train.BaselineStageTrainer(opt, netG, netD)
     rec = fx["iters"][0]
     netG.noise_source = NoiseFeed(rec["noises"], dev)
+    # each critic update is judged on its own and then replaced by the reference's (helpers.run_hip_stage explains why)
+    hip_d_steps = []
+
+    def hook(t, j):
+        hip_d_steps.append({k: v.detach().clone() for k, v in t.netD.state_dict().items()})
+        t.netD.load_state_dict(rec["D_steps"][j])
+    tr.after_d_step = hook
     out = tr.step(fx["real"].to(dev), noise_init=rec["noise_init"].to(dev), alphas=rec["alphas"])
     assert opt.Noise_Amps == pytest.approx(rec["noise_amps"], rel=1e-4)
     from helpers import _bn_fed_bias, compare_step, compare_update
@@ -154,15 +162,18 @@ def test_baseline_singan_step_matches_reference(fname, generator, critic):
         else:
             assert_close(sdG[k].float(), v.float(), RTOL, "baseline.G_after." + k, atol=max(1e-6, 2 * spread["G_after"].get(k, 0.0)))
     dnames = dict(netD.named_parameters())
-    for k, v in rec["D_after"].items():
-        if k in dnames:
-            sf = 0.05 if spread["D_after"].get(k, 0.0) > opt.lr_d / 10 else 0.0
-            compare_update("baseline.D." + k, fx["D_init"][k], v, sdD[k], opt.lr_d, sf, _bn_fed_bias(k, set(dnames)),
-                           first_step=(opt.Dsteps == 1))
-        elif k.endswith("num_batches_tracked"):
-            assert int(sdD[k]) == int(v), k
-        else:
-            assert_close(sdD[k].float(), v.float(), RTOL, "baseline.D_after." + k, atol=max(1e-6, 2 * spread["D_after"].get(k, 0.0)))
+    assert len(hip_d_steps) == opt.Dsteps == len(rec["D_steps"])
+    for j in range(opt.Dsteps):
+        before = fx["D_init"] if j == 0 else rec["D_steps"][j - 1]
+        for k, v in rec["D_steps"][j].items():
+            mine = hip_d_steps[j][k]
+            if k in dnames:
+                sf = 0.05 if spread["D_after"].get(k, 0.0) > opt.lr_d / 10 else 0.0
+                compare_update("baseline.D[%d].%s" % (j, k), before[k], v, mine, opt.lr_d, sf, _bn_fed_bias(k, set(dnames)), first_step=(j == 0))
+            elif k.endswith("num_batches_tracked"):
+                assert int(mine) == int(v), k
+            else:
+                assert_close(mine.float(), v.float(), RTOL, "baseline.D[%d].%s" % (j, k), atol=max(1e-6, 2 * spread["D_after"].get(k, 0.0)))
 
 
 @pytest.mark.parametrize("fname", ["step3d_gan_s3.pt", "step3d_vae_s1.pt"])
