@@ -123,15 +123,18 @@ def run_hip_stage(fx, device="cuda", sync=True):
     real, real_zero = fx["real"].to(device), fx["real_zero"].to(device)
     prev = None
     for rec in fx["iters"]:
-        if sync and prev is not None:
+        if sync and prev is not None and "G_after" in prev:
             netG.load_state_dict(prev["G_after"])
             if netD is not None:
                 netD.load_state_dict(prev["D_after"])
         hip_d = {}
-        if sync and netD is not None:
+        if sync and netD is not None and rec.get("D_after") is not None:
             def hook(tr, rec=rec, hip_d=hip_d):
                 hip_d.update({k: v.detach().clone() for k, v in tr.netD.state_dict().items()})
-                tr.netD.load_state_dict(rec["D_after"])
+                # PARAMETERS only: D_after was recorded at the end of the iteration, when the spectral-norm u / v had seen
+                # one more forward (the generator step's) than they have at this point
+                pnames = set(n for n, _ in tr.netD.named_parameters())
+                tr.netD.load_state_dict({k: v for k, v in rec["D_after"].items() if k in pnames}, strict=False)
             trainer.after_d_step = hook
         netG.noise_source = NoiseFeed(rec["noises"], device)
         alpha = rec["alpha"] if rec["alpha"] is not None else None

@@ -62,7 +62,8 @@ def test_train_step_matches_reference(fname):
                     sf = 0.05 if (spread is not None and spread["D_after"].get(k, 0.0) > fx["opt"]["lr_d"] / 10) else 0.0
                     compare_update(what + ".D." + k, prevD[k], v, sdD[k], fx["opt"]["lr_d"], sf, False, first_step=(it == 0))
                 else:
-                    assert_close(sdD[k].float(), v.float(), RTOL, what + ".D_after." + k, atol=max(1e-6, 2 * (spread or {}).get("D_after", {}).get(k, 0.0)))
+                    # buffers (spectral-norm u / v): as they stand at the END of the iteration, like the recorded ones
+                    assert_close(netD.state_dict()[k].float(), v.float(), RTOL, what + ".D_after." + k, atol=max(1e-6, 2 * (spread or {}).get("D_after", {}).get(k, 0.0)))
             prevD = {k: v.clone() for k, v in rec["D_after"].items()}
 
 
