@@ -18,9 +18,28 @@ def load(path, counter):
     return {k: v[0] / v[1] for k, v in acc.items()}
 
 
+json_out = None
+if "--roofline-json" in sys.argv:
+    i = sys.argv.index("--roofline-json")
+    json_out = sys.argv[i + 1]          # then: <csv path to cite> <B> <C> <T> <H> <W>
+    cite, shape = sys.argv[i + 2], [int(v) for v in sys.argv[i + 3:i + 8]]
+    del sys.argv[i:i + 8]
 f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
 print("kernel,grid,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected")
 for k in sorted(set(f) | set(w)):
     fk, wk = f.get(k, 0.0), w.get(k, 0.0)
     print("%s,%s,%.4g,%.4g,%.4g" % (k[0].replace(",", ";"), k[1], fk, wk, 2 * fk * 1024 + wk * 1024))
+
+if json_out:
+    # the roofline kernel of bench.py: the 64->64 3x3x3 conv instance with the largest fetch (the full-resolution launch of
+    # tools/perf_conv.py at that shape) + the largest stream-K fix-up launch that follows it
+    import json
+    rows = {k: 2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024 for k in set(f) | set(w)}
+    main = max((k for k in rows if "conv_mfma_kernel<8" in k[0] and k[0].rstrip(">").endswith(" 0")), key=lambda k: rows[k])
+    fix = max((k for k in rows if "conv_fixup_kernel" in k[0]), key=lambda k: rows[k])
+    ent = {"shape": shape, "bytes": round(rows[main] + rows[fix]), "source": cite,
+           "rows": {"%s grid %s" % main: round(rows[main]), "%s grid %s" % fix: round(rows[fix])}}
+    json.dump({"note": "HBM bytes per launch of bench.py's roofline kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                       "(gfx950: FETCH_SIZE x 2; tools/pmc_summary.py); bench.py reports `traffic` from here", "entries": [ent]},
+              open(json_out, "w"), indent=1)
