@@ -575,6 +575,234 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const ConvFwdArgs a
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Narrow-output convolution, second generation (Cout <= 4, Cin even, no prologue / mask): same GEMM as conv_narrow_kernel
+// (M = positions, N = (o, dh, dw), K = (c, dt); P through LDS, shifted 9-term sums as the epilogue) with the input
+// streamed by 16-BYTE loads.  conv_narrow_kernel issues one dword load per lane per MFMA (vector-memory issue bound:
+// 0.43 ms at stage 9 against an MFMA floor of ~0.12 ms).  Here a lane loads FOUR consecutive positions of one
+// (channel, plane) with one global_load_dwordx4 and feeds them to four MFMAs as the A operand of four different
+// 32-position blocks: MFMA j of a 128-position group computes the P rows of positions {128 g + 4 i + j, i = 0..31} - the
+// M index of an MFMA is just a label, the P store puts every row where it belongs.  The weight fragment of a k-step is
+// loaded once per four MFMAs.  For that every group of 4 positions must be contiguous in memory and inside the image:
+// a tile is (Th + 2) rows x RS columns (RS % 4 == 0) of a column WINDOW that lies inside [0, W) - no halo columns are
+// fetched from outside the image (band 0 starts at column 0, the last band ends at W; an output at the image border skips
+// its out-of-image taps in the epilogue); rows outside the image are clamped for the load and zeroed by select.
+struct Narrow2Geom {
+  int RS, Th, nth, nb, npos, G, pitch;
+  int ws[16], ob[16], on[16];  // per band: window start column, first output column, number of output columns
+};
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int JB> struct AVecU;
+template <> struct AVecU<4> { typedef f32x4u type; };
+template <> struct AVecU<2> { typedef f32x2u type; };
+
+template <int KT, int NT, int JB>
+__global__ __launch_bounds__(256, 2) void conv_narrow2_kernel(const ConvFwdArgs a, const Narrow2Geom g, int ksteps) {
+  typedef typename AVecU<JB>::type AV;
+  constexpr int GP = 32 * JB;                 // positions per group (one lane: JB consecutive positions)
+  constexpr int KC = KT == 3 ? 6 : 8;         // k-steps per register set (a multiple of KT: the plane of step j is j % KT)
+  extern __shared__ __attribute__((aligned(16))) float P[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const long HW = (long)a.H * a.W;
+  const int RS = g.RS, pitch = g.pitch;
+  const int CO9 = a.Cout * 9;
+  const int pt = (KT == 3 ? 1 : 0);
+
+  // tile order: band fastest, then TIME, then the row block: consecutive workgroups (one XCD) share input planes t-1, t, t+1
+  int r = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const int band = r % g.nb; r /= g.nb;
+  const int t = r % a.T; r /= a.T;
+  const int th = r % g.nth;
+  const int b = r / g.nth;
+  const int h0 = th * g.Th, wsb = g.ws[band];
+  const float* xs = a.x + ((long)b * a.Cin * a.T + (t - pt)) * HW;      // plane (c = 0, dt = 0) of this tile
+  const int chalf = (ksteps / KT) * half;                                // first channel of this half-wave's K range
+
+  for (int grp = wave; grp < g.G; grp += 4) {
+    const int p = GP * grp + JB * l31;
+    const int pc = p < g.npos ? p : g.npos - JB;
+    const int row = pc / RS, col = pc - row * RS;
+    const int gh = h0 - 1 + row;
+    const bool valid = p < g.npos && gh >= 0 && gh < a.H;
+    const int ghc = gh < 0 ? 0 : (gh >= a.H ? a.H - 1 : gh);
+    const float* lp = xs + (long)chalf * a.T * HW + (long)ghc * a.W + wsb + col;
+    const float* wq = a.wp + lane;
+    f32x16 acc[JB][NT];
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][nt][e] = 0.f;
+    bool tok[KT];
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt) tok[dt] = (t + dt - pt >= 0) && (t + dt - pt < a.T);
+    AV av[2][KC];
+    float bv[2][KC][NT];
+    auto load_chunk = [&](AV (&A)[KC], float (&Bf)[KC][NT], int s0) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int s = s0 + j;
+        const int dt = j % KT;                                // s0 is a multiple of KT
+        const int cs = s0 / KT + j / KT;                      // channel of this step inside the half-wave's range
+        if (s < ksteps && tok[dt]) {                          // uniform
+          A[j] = *reinterpret_cast<const AV*>(lp + ((long)cs * a.T + dt) * HW);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) Bf[j][nt] = wq[(s * NT + nt) * 64];
+        }
+      }
+    };
+    auto mma_chunk = [&](const AV (&A)[KC], const float (&Bf)[KC][NT], int s0) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int s = s0 + j;
+        if (s < ksteps && tok[j % KT]) {
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj) {
+            const float v = valid ? A[j][jj] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[jj][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, Bf[j][nt], acc[jj][nt], 0, 0, 0);
+          }
+        }
+      }
+    };
+    load_chunk(av[0], bv[0], 0);
+    for (int s0 = 0; s0 < ksteps; s0 += 2 * KC) {
+      load_chunk(av[1], bv[1], s0 + KC);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(av[0], bv[0], s0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(av[0], bv[0], s0 + 2 * KC);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(av[1], bv[1], s0 + KC);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D layout: column (n) = lane & 31, row i = (e & 3) + 8 * (e >> 2) + 4 * half; row i of MFMA jj = position GP*grp + JB*i + jj
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 32 + l31;
+      if (n < CO9) {
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) P[n * pitch + GP * grp + JB * ((e & 3) + 8 * (e >> 2) + 4 * half) + jj] = acc[jj][nt][e];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: shifted 9-term sums (taps outside the image skipped: the window holds no zero-padding columns), bias
+  // after the accumulation, optional LeakyReLU
+  const int ob = g.ob[band], on = g.on[band];
+  const int nout = g.Th * on;
+  for (int idx = tid; idx < nout; idx += 256) {
+    const int hh = idx / on, cc = idx - hh * on;
+    const int gh = h0 + hh, gw = ob + cc;
+    if (gh >= a.H) continue;
+    const long sp = (long)t * HW + (long)gh * a.W + gw;
+    for (int o = 0; o < a.Cout; ++o) {
+      float v = 0.f;
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const int gwt = gw + dw - 1;
+          if (gwt >= 0 && gwt < a.W) v += P[(o * 9 + dh * 3 + dw) * pitch + (hh + dh) * RS + (gwt - wsb)];
+        }
+      if (a.bias) v += a.bias[o];
+      if (a.out_lrelu) v = hpvg_lrelu(v);
+      a.y[((long)b * a.Cout + o) * a.T * HW + sp] = v;
+    }
+  }
+}
+
+// tile plan of conv_narrow2_kernel; returns false when the shape does not fit (then conv_narrow_kernel runs)
+bool plan_narrow2(int B, int Cin, int Cout, int T, int H, int W, int KT, Narrow2Geom* out, long* ntiles) {
+  if ((Cin & 1) || W < 4) return false;
+  const int NT = hpvg_cdiv(9 * Cout, 32);
+  const int JB = NT == 1 ? 4 : 2;
+  const int GP = 32 * JB;
+  double best = 1e300;
+  bool found = false;
+  // bands of a window width RS: band 0 = window [0, RS), outputs columns 0 .. RS-2 (all W of them when RS == W); a middle
+  // band outputs RS-2 columns from the window that starts one column before its first output; a band whose remaining
+  // columns number <= RS-1 is the last: its window is pulled back to end at W (the right image border needs no neighbour)
+  auto bands = [&](int RS, Narrow2Geom* q) -> int {
+    int nb = 0, o = 0;
+    while (o < W) {
+      if (nb == 16) return 0;
+      int n, ws;
+      if (nb == 0) { n = (RS == W) ? W : RS - 1; ws = 0; }
+      else if (W - o <= RS - 1) { n = W - o; ws = W - RS; }
+      else { n = RS - 2; ws = o - 1; }
+      if (n < 1) return 0;
+      if (q) { q->ws[nb] = ws; q->ob[nb] = o; q->on[nb] = n; }
+      o += n;
+      ++nb;
+    }
+    return nb;
+  };
+  for (int RS = 4; RS <= 256 && RS <= W; RS += 4) {
+    const int nb = bands(RS, nullptr);
+    if (nb == 0) continue;
+    for (int Th = 1; Th <= H; ++Th) {
+      const int nth = hpvg_cdiv(H, Th);
+      if (Th != hpvg_cdiv(H, nth)) continue;
+      const int npos = (Th + 2) * RS;
+      const int G = hpvg_cdiv(npos, GP);
+      if (G > 16) break;
+      const int pitch = (G * GP) | 1;
+      if ((size_t)(9 * Cout) * pitch * sizeof(float) > 76 * 1024) break;
+      const long nt = (long)B * T * nth * nb;
+      const double rounds = hpvg_cdiv(G, 4);
+      const double waves = nt <= 2L * HPVG_NUM_CU ? 1.0 : (double)nt / (2.0 * HPVG_NUM_CU);
+      const double cost = waves * (rounds * GP + 30.0);     // MFMA work of the slowest wave + a fixed per-tile cost (epilogue, barrier)
+      if (cost < best) {
+        best = cost;
+        found = true;
+        Narrow2Geom q{};
+        q.RS = RS; q.Th = Th; q.nth = nth; q.nb = nb; q.npos = npos; q.G = G; q.pitch = pitch;
+        bands(RS, &q);
+        *out = q;
+        *ntiles = nt;
+      }
+    }
+  }
+  if (!found) return false;
+  // every output column needs its in-image neighbours inside the band's window
+  for (int k = 0; k < out->nb; ++k) {
+    const int lo = out->ob[k] - 1 < 0 ? 0 : out->ob[k] - 1;
+    const int hi = out->ob[k] + out->on[k] > W - 1 ? W - 1 : out->ob[k] + out->on[k];
+    if (out->on[k] < 0 || lo < out->ws[k] || hi >= out->ws[k] + out->RS) return false;
+  }
+  return true;
+}
+
+template <int KT>
+int launch_conv_narrow2(const ConvFwdArgs& a, const Narrow2Geom& g, long ntiles, hipStream_t s) {
+  const int ksteps = hpvg_cdiv(a.Cin * KT, 2);
+  const size_t lds = (size_t)(9 * a.Cout) * g.pitch * sizeof(float);
+#define HPVG_NARROW2(NT, JB)                                                                                         \
+  {                                                                                                                  \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_narrow2_kernel<KT, NT, JB>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                 \
+        (void)hipGetLastError();                                                                                     \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((conv_narrow2_kernel<KT, NT, JB>), dim3((unsigned)ntiles), dim3(256), lds, s, a, g, ksteps);  \
+  }
+  if (9 * a.Cout <= 32) HPVG_NARROW2(1, 4) else HPVG_NARROW2(2, 2)
+#undef HPVG_NARROW2
+  return hpvg_launch_status();
+}
+
 // B fragments of the narrow kernel; transpose_flip as in conv_pack_kernel
 __global__ void conv_pack_narrow_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, float* __restrict__ wn,
                                         int Cin_k, int Cout_k, int KT, int NT, int ksteps, int transpose_flip, long total) {
@@ -1000,6 +1228,12 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   a.ntl = ntl;
   if (conv_is_narrow(Cin, Cout)) {
     a.ndp = 1; a.skbase = ntl; a.skpart = nullptr;
+    // development knob: HPVG_NARROW2=0 keeps the first-generation kernel
+    static const bool n2_off = [] { const char* e = getenv("HPVG_NARROW2"); return e && atoi(e) == 0; }();
+    Narrow2Geom g2;
+    long nt2 = 0;
+    if (!n2_off && !in_scale && !out_mask && plan_narrow2(B, Cin, Cout, T, H, W, KT, &g2, &nt2))
+      return KT == 3 ? launch_conv_narrow2<3>(a, g2, nt2, (hipStream_t)stream) : launch_conv_narrow2<1>(a, g2, nt2, (hipStream_t)stream);
     return KT == 3 ? launch_conv_narrow<3>(a, p, (hipStream_t)stream) : launch_conv_narrow<1>(a, p, (hipStream_t)stream);
   }
   const int S = streamk ? conv_sk_grid(ntl, nchunk, p) : ntl;  // S = ntl: one data-parallel round, no stream-K part
@@ -1028,6 +1262,19 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
   out[0] = p.L; out[1] = p.Tw; out[2] = p.nrange; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
   out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nrange * p.ntw;
+  return HPVG_OK;
+}
+
+// Debug/introspection: the tile plan of the narrow-output kernel (conv_narrow2_kernel) for tests: out[0..6] = RS, Th, nth,
+// nb, npos, G, pitch, then nb triples (window start, first output column, output columns).  Returns HPVG_ERR_UNSUPPORTED
+// when the shape runs on the first-generation kernel instead.
+int hpvg_conv_narrow_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  Narrow2Geom g;
+  long nt = 0;
+  if (!conv_is_narrow(Cin, Cout) || !plan_narrow2(B, Cin, Cout, T, H, W, KT, &g, &nt)) return HPVG_ERR_UNSUPPORTED;
+  out[0] = g.RS; out[1] = g.Th; out[2] = g.nth; out[3] = g.nb; out[4] = g.npos; out[5] = g.G; out[6] = g.pitch;
+  for (int k = 0; k < g.nb; ++k) { out[7 + 3 * k] = g.ws[k]; out[8 + 3 * k] = g.ob[k]; out[9 + 3 * k] = g.on[k]; }
   return HPVG_OK;
 }
 

@@ -52,6 +52,9 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
                       int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
                       int Cout, int T, int H, int W, int KT, void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
+/* host only: tile plan of the narrow-output kernel (Cout <= 4): out[0..6] = RS, Th, nth, nb, npos, G, pitch, then nb triples
+ * (window start, first output column, output columns); out needs 7 + 3*16 ints */
+int hpvg_conv_narrow_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out55);
 /* dW (natural layout) of the conv above: aten::convolution_backward weight half, reached from
  * total_loss.backward() / errD_total.backward() (train_video.py:182,200). accumulate!=0: dw += result. */
 size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT);

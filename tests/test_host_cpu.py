@@ -203,3 +203,33 @@ def test_flat_adam_state_dict_is_torch_adams(tmp_path):
             assert float(st["step"]) == 7.0
             assert torch.equal(st["exp_avg"], grp["m"][o - grp["lo"]:o - grp["lo"] + n].view(p.shape))
             assert torch.equal(st["exp_avg_sq"], grp["v"][o - grp["lo"]:o - grp["lo"] + n].view(p.shape))
+
+
+def test_narrow_conv_plan_keeps_every_load_inside_the_image():
+    """conv_narrow2_kernel streams its input with 16-byte loads from column WINDOWS that must lie inside the image (nothing
+    zeroes a halo column, nothing may be read before / after the tensor): host-side check of the planner's band table over
+    every width the pyramids (and the padded baseline volumes) can produce."""
+    import ctypes
+    from hp_vae_gan_amd import lib as hplib
+    lib = hplib.load()
+    out = (ctypes.c_int * 55)()
+    for Cout in (1, 3, 4):
+        JB = 4 if 9 * Cout <= 32 else 2
+        for W in list(range(4, 300)) + [512, 1000]:
+            for H in (1, 3, 18, 91, 144):
+                rc = lib.hpvg_conv_narrow_plan(2, 64, Cout, 5, H, W, 3, out)
+                assert rc == 0, (Cout, W, H, rc)
+                RS, Th, nth, nb, npos, G, pitch = list(out[:7])
+                assert RS % 4 == 0 and 4 <= RS <= W and npos == (Th + 2) * RS and G * 32 * JB >= npos and pitch >= G * 32 * JB
+                assert nth * Th >= H and (nth - 1) * Th < H
+                assert 9 * Cout * pitch * 4 <= 76 * 1024
+                nxt = 0
+                for k in range(nb):
+                    ws, ob, on = out[7 + 3 * k], out[8 + 3 * k], out[9 + 3 * k]
+                    assert 0 <= ws and ws + RS <= W, (W, RS, k, ws)               # the window lies inside the image
+                    assert ob == nxt and on >= 1                                  # outputs tile [0, W) without gaps
+                    assert max(ob - 1, 0) >= ws and min(ob + on, W - 1) <= ws + RS - 1   # in-image neighbours are in the window
+                    nxt = ob + on
+                assert nxt == W
+    assert lib.hpvg_conv_narrow_plan(2, 5, 3, 5, 9, 16, 3, out) != 0    # odd Cin: first-generation kernel
+    assert lib.hpvg_conv_narrow_plan(2, 64, 3, 5, 9, 3, 3, out) != 0    # narrower than one 16-byte group
