@@ -606,6 +606,52 @@ __global__ __launch_bounds__(256) void gp_bwd_kernel(const float* __restrict__ g
   }
 }
 
+// ------------------------------------------------------------------ N(0,1) noise: Philox4x32-10 + Box-Muller
+// utils/images.py:49 (zeros(...).normal_(0, 1)) and networks_3d.py:32 (the reparameterisation eps).  Counter-based, so a
+// draw needs no generator state in memory: element quadruple q of call `call_id` in iteration iter[0] under `seed` is
+// philox(counter = (q_lo, q_hi, call_id, iter[0]), key = seed).  `iter` lives on the device and is bumped once per train
+// iteration by hpvg_counter_inc_i32 - a replayed hipGraph draws fresh noise without any launch argument changing.
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// four N(0,1) values from one Philox block (two Box-Muller pairs; uniforms in (0, 1) from the top 24 bits)
+__device__ __forceinline__ void philox_normal4(long q, unsigned call_id, unsigned iter, unsigned long long seed, float (&n)[4]) {
+  const Philox4 r = philox4x32_10((unsigned)q, (unsigned)((unsigned long long)q >> 32), call_id, iter, (unsigned)seed,
+                                  (unsigned)(seed >> 32));
+  const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.f / 16777216.f);
+  const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(r.w >> 8) + 0.5f) * (1.f / 16777216.f);
+  const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u1, &sa, &ca);
+  sincosf(6.283185307179586f * u3, &sb, &cb);
+  n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+}
+__global__ __launch_bounds__(256) void normal_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned call_id,
+                                                      const int* __restrict__ iter) {
+  const unsigned it = iter ? (unsigned)iter[0] : 0u;
+  const long nq = (n + 3) / 4;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    float v[4];
+    philox_normal4(q, call_id, it, seed, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < n) out[4 * q + e] = v[e];
+  }
+}
+
 // ------------------------------------------------------------------ tri/bi-linear resize, align_corners=True
 // utils/images.py:13,17,24 (F.interpolate(..., align_corners=True)).  src = dst*(in-1)/(out-1) in fp32.
 struct Lin { int i0, i1; float w0, w1; };
@@ -648,6 +694,49 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
     if (yn) yn[i] = acc + amp * noise[i];
   }
 }
+// The same with the level noise GENERATED in the kernel (networks_3d.py:395-400: up + noise * amp with noise ~ N(0, 1)): the
+// noise tensor never exists in memory.  Samples (bc / C) below `first_noisy` get no noise (the reconstruction half of a
+// merged generator pass).  Element i of the output uses value i % 4 of Philox block i / 4 - what normal_kernel writes.
+__global__ __launch_bounds__(256) void upsample_noise_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  float* __restrict__ yn, float amp, long BC, int C, int first_noisy,
+                                                                  int Ti, int Hi, int Wi, int To, int Ho, int Wo, float st, float sh,
+                                                                  float sw, unsigned long long seed, unsigned call_id,
+                                                                  const int* __restrict__ iter) {
+  const unsigned it = iter ? (unsigned)iter[0] : 0u;
+  const long n = BC * To * Ho * Wo;
+  const long nq = (n + 3) / 4;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    float nz[4];
+    philox_normal4(q, call_id, it, seed, nz);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = 4 * q + e;
+      if (i >= n) break;
+      long r = i;
+      const int wo = r % Wo; r /= Wo;
+      const int ho = r % Ho; r /= Ho;
+      const int to = r % To; r /= To;
+      const float* xp = x + r * ((long)Ti * Hi * Wi);
+      const Lin lt = lin_coef(to, Ti, st), lh = lin_coef(ho, Hi, sh), lw = lin_coef(wo, Wi, sw);
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ti = a ? lt.i1 : lt.i0;
+        const float wt = a ? lt.w1 : lt.w0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int hi = b ? lh.i1 : lh.i0;
+          const float wh = b ? lh.w1 : lh.w0;
+          const float* row = xp + ((long)ti * Hi + hi) * Wi;
+          acc += wt * wh * (lw.w0 * row[lw.i0] + lw.w1 * row[lw.i1]);
+        }
+      }
+      y[i] = acc;
+      yn[i] = (int)(r / C) >= first_noisy ? acc + amp * nz[e] : acc;
+    }
+  }
+}
+
 // Backward of the resize as a GATHER: one thread per INPUT voxel sums, in a fixed order, the contributions of the output
 // voxels whose interpolation touches it (no float atomics, no pre-zeroed buffer: bitwise reproducible).  Per axis the
 // candidate outputs of input index i are those with src = scale*o in (i-1, i+1); the exact membership test re-evaluates
@@ -1335,6 +1424,23 @@ int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, fl
   const long n = BC * To * Ho * Wo;
   hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, noise, amp, yn, BC, Ti,
                      Hi, Wi, To, Ho, Wo, ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  return hpvg_launch_status();
+}
+// N(0,1) fill (Philox4x32-10 + Box-Muller): out[i] = value (i % 4) of block i / 4 of stream (seed, call_id, iter[0]); iter may be NULL (0)
+int hpvg_normal_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream) {
+  if (!out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(normal_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, call_id, iter);
+  return hpvg_launch_status();
+}
+// y = resize(x); yn = y + amp * N(0,1) with the noise of hpvg_normal_f32(stream (seed, call_id, iter)) generated in the kernel;
+// samples b < first_noisy get yn = y.  C = channels per sample (BC = batch * C).
+int hpvg_upsample_linear_ac_noise_f32(const float* x, float* y, float* yn, float amp, long BC, int C, int first_noisy, int Ti, int Hi,
+                                      int Wi, int To, int Ho, int Wo, unsigned long long seed, unsigned call_id, const int* iter,
+                                      void* stream) {
+  if (!x || !y || !yn || BC < 1 || C < 1 || Ti < 1 || Hi < 1 || Wi < 1 || To < 1 || Ho < 1 || Wo < 1) return HPVG_ERR_ARG;
+  const long n = BC * To * Ho * Wo;
+  hipLaunchKernelGGL(upsample_noise_fwd_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, yn, amp, BC, C,
+                     first_noisy, Ti, Hi, Wi, To, Ho, Wo, ac_scale(Ti, To), ac_scale(Hi, Ho), ac_scale(Wi, Wo), seed, call_id, iter);
   return hpvg_launch_status();
 }
 int hpvg_upsample_linear_ac_bwd_f32(const float* dy, const float* dy2, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho,

@@ -69,6 +69,8 @@ _SIGS = {
     "hpvg_gp_fwd_f32": [P, P, F, P, Z, I, I, L, P],
     "hpvg_gp_bwd_f32": [P, P, P, F, I, I, L, P],
     "hpvg_upsample_linear_ac_f32": [P, P, P, F, P, L, I, I, I, I, I, I, P],
+    "hpvg_normal_f32": [P, L, ctypes.c_ulonglong, ctypes.c_uint, P, P],
+    "hpvg_upsample_linear_ac_noise_f32": [P, P, P, F, L, I, I, I, I, I, I, I, I, ctypes.c_ulonglong, ctypes.c_uint, P, P],
     "hpvg_frames_resize_norm_u8_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "hpvg_upsample_linear_ac_bwd_f32": [P, P, P, L, I, I, I, I, I, I, P],
     "hpvg_sn_power_iter_f32": [P, P, P, P, P, P, I, I, I, F, P, Z, P],

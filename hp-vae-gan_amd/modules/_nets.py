@@ -356,9 +356,13 @@ class GeneratorHPVAEGAN(nn.Module):
                     x.detach_()
                 size = self._level_size(idx + 1)
                 if self.dims == 2 or self.opt.vae_levels <= idx + 1:   # levels where the rand pass injects noise
-                    ref = x.new_empty((B, x.shape[1], *size))
-                    noise = ops.concat_batch([B, self._noise_like(ref)])   # zero noise for the rec half
-                    up, up_noisy = ops.UpsampleAC.apply(x, tuple(size), noise, float(noise_amp[idx + 1]))
+                    if self.noise_source is None:
+                        # noise generated inside the resize kernel, for the rand half only
+                        up, up_noisy = ops.UpsampleACNoise.apply(x, tuple(size), float(noise_amp[idx + 1]), B)
+                    else:
+                        ref = x.new_empty((B, x.shape[1], *size))
+                        noise = ops.concat_batch([B, self._noise_like(ref)])   # zero noise for the rec half
+                        up, up_noisy = ops.UpsampleAC.apply(x, tuple(size), noise, float(noise_amp[idx + 1]))
                 else:
                     up = up_noisy = ops.UpsampleAC.apply(x, tuple(size), None, 0.0)
                 x = ops.TanhRes.apply(block(up_noisy), up)
@@ -379,7 +383,9 @@ class GeneratorHPVAEGAN(nn.Module):
                 x_prev_out.detach_()
             size = self._level_size(idx + 1)
             inject = mode == 'rand' and (self.dims == 2 or self.opt.vae_levels <= idx + 1)
-            if inject:
+            if inject and self.noise_source is None:
+                up, up_noisy = ops.UpsampleACNoise.apply(x_prev_out, tuple(size), float(noise_amp[idx + 1]), 0)   # noise made in the kernel
+            elif inject:
                 ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *size))
                 noise = self._noise_like(ref)
                 up, up_noisy = ops.UpsampleAC.apply(x_prev_out, tuple(size), noise, float(noise_amp[idx + 1]))
@@ -450,9 +456,11 @@ class GeneratorSG(nn.Module):
             up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
             if mode == 'rand':
                 big = tuple(s + 2 * self.pad for s in size)
-                ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
-                noise = self.noise_source(ref) if self.noise_source is not None else hp_utils.generate_noise(ref=ref)
-                _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, noise, float(noise_amp[idx]))
+                if self.noise_source is None:
+                    _, up2_noisy = ops.UpsampleACNoise.apply(x_prev_out, big, float(noise_amp[idx]), 0)
+                else:
+                    ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
+                    _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, self.noise_source(ref), float(noise_amp[idx]))
                 x_prev = block(up2_noisy)
             else:
                 x_prev = block(self._zero_pad(up))
@@ -498,9 +506,11 @@ class GeneratorCSG(nn.Module):
             up = ops.UpsampleAC.apply(x_prev_out, tuple(size), None, 0.0)
             if mode == 'rand':
                 big = tuple(s + 2 * p for s in size)
-                ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
-                noise = self.noise_source(ref) if self.noise_source is not None else hp_utils.generate_noise(ref=ref)
-                _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, noise, float(noise_amp[idx]))
+                if self.noise_source is None:
+                    _, up2_noisy = ops.UpsampleACNoise.apply(x_prev_out, big, float(noise_amp[idx]), 0)
+                else:
+                    ref = x_prev_out.new_empty((x_prev_out.shape[0], x_prev_out.shape[1], *big))
+                    _, up2_noisy = ops.UpsampleAC.apply(x_prev_out, big, self.noise_source(ref), float(noise_amp[idx]))
                 x_prev = block(up2_noisy)
             else:
                 x_prev = block(self._zero_pad(up, p))

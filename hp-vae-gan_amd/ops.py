@@ -779,6 +779,85 @@ class UpsampleAC(Function):
         return dx, None, None, None
 
 
+# ------------------------------------------------------------------------------------------ N(0,1) noise (Philox kernel)
+class _RngState:
+    """Counter-based noise stream of one device: (seed, iteration counter ON THE DEVICE, call index inside the iteration).
+    The kernels read the iteration from device memory, so a hipGraph replay draws fresh noise although none of its launch
+    arguments changes; the trainers bump it once per iteration (rng_next_iteration)."""
+
+    def __init__(self, device):
+        self.iter_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.call = 0
+
+
+_rng_states = {}
+
+
+def _rng(device):
+    key = (device.type, device.index)
+    st = _rng_states.get(key)
+    if st is None:
+        st = _rng_states[key] = _RngState(device)
+    return st
+
+
+def rng_next_iteration(device):
+    """Start the noise stream of the next train iteration on `device` (one 1-thread kernel; captured with the iteration)."""
+    st = _rng(torch.device(device) if not isinstance(device, torch.device) else device)
+    counter_inc_(st.iter_dev)
+    st.call = 0
+
+
+def _seed():
+    return ctypes.c_ulonglong(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)   # follows torch.manual_seed
+
+
+def normal_(out):
+    """out <- N(0, 1) (utils/images.py:49, networks_3d.py:32) with the Philox kernel of libhpvg; returns out."""
+    st = _rng(out.device)
+    call("hpvg_normal_f32", ptr(out), ctypes.c_long(out.numel()), _seed(), ctypes.c_uint(st.call & 0xFFFFFFFF), ptr(st.iter_dev), stream())
+    st.call += 1
+    return out
+
+
+class UpsampleACNoise(Function):
+    """(up, up + amp * N(0,1)) with the level noise generated inside the resize kernel (no noise tensor in memory);
+    samples below `first_noisy` get no noise (the reconstruction half of a merged generator pass).  Same backward as
+    UpsampleAC (the noise carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, size, amp, first_noisy):
+        x = _c(x)
+        B, C, Ti, Hi, Wi = geom(x)
+        if x.dim() == 5:
+            To, Ho, Wo = size
+            oshape = (B, C, To, Ho, Wo)
+        else:
+            Ho, Wo = size
+            To = 1
+            oshape = (B, C, Ho, Wo)
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        yn = torch.empty_like(y)
+        st = _rng(x.device)
+        call("hpvg_upsample_linear_ac_noise_f32", ptr(x), ptr(y), ptr(yn), float(amp), ctypes.c_long(B * C), C, int(first_noisy), Ti,
+             Hi, Wi, To, Ho, Wo, _seed(), ctypes.c_uint(st.call & 0xFFFFFFFF), ptr(st.iter_dev), stream())
+        st.call += 1
+        ctx.in_shape = x.shape
+        ctx.dims = (B * C, Ti, Hi, Wi, To, Ho, Wo)
+        return y, yn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, dyn):
+        g, g2 = (dy, dyn) if dy is not None else (dyn, None)
+        g = _c(g)
+        g2 = _c(g2) if g2 is not None else None
+        BC, Ti, Hi, Wi, To, Ho, Wo = ctx.dims
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=g.device)
+        call("hpvg_upsample_linear_ac_bwd_f32", ptr(g), ptr(g2), ptr(dx), ctypes.c_long(BC), Ti, Hi, Wi, To, Ho, Wo, stream())
+        return dx, None, None, None
+
+
 class Reparam(Function):
     """z = eps * exp(0.5*logvar) + mu (networks_3d.py:29-33, training branch)."""
 

@@ -162,6 +162,8 @@ class StageTrainer:
 
     def _step_eager(self, real, real_zero, noise_init=None, alpha=None):
         opt, netG = self.opt, self.netG
+        if real.is_cuda:
+            ops.rng_next_iteration(real.device)   # the library's noise stream: (seed, iteration on the device, call index)
         if alpha is None and getattr(self, '_graph_alpha', False):
             alpha = torch.rand(1, device=real.device)
         if noise_init is None:
@@ -285,6 +287,8 @@ class BaselineStageTrainer:
 
     def step(self, real, noise_init=None, alphas=None):
         opt, netG, netD = self.opt, self.netG, self.netD
+        if real.is_cuda:
+            ops.rng_next_iteration(real.device)
         if noise_init is None:
             noise_init = utils.generate_noise(ref=opt.Z_init)
         if self.iteration == 0:

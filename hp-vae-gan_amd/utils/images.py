@@ -58,8 +58,10 @@ def adjust_scales2image(size, opt):
 
 
 def generate_noise(ref=None, size=None, type='normal', emb_size=None, device=None):
-    """Noise tensor shaped like `ref` or `size` (reference: utils/images.py:39-57).  Random bits come from torch's
-    generator of the target device (the CPU generator when opt-in parity mode hands CPU noise in)."""
+    """Noise tensor shaped like `ref` or `size` (reference: utils/images.py:39-57).  N(0, 1) on the device comes from the
+    library's own counter-based kernel (hpvg_normal_f32; seeded by torch.manual_seed, advanced per train iteration on the
+    device so that hipGraph replays draw fresh noise); the other types and host tensors use torch's generators.  No device
+    stream can reproduce the reference's CPU mt19937 draws: parity tests inject recorded noise instead."""
     # (the reference fills zeros first; every element is overwritten by the draw below, and torch.zeros is a
     # hipMemsetAsync, whose node inside a captured hipGraph is not reliably ordered on this runtime - see elementwise.hip)
     if ref is not None:
@@ -70,6 +72,8 @@ def generate_noise(ref=None, size=None, type='normal', emb_size=None, device=Non
         raise Exception("ref or size must be applied")
 
     if type == 'normal':
+        if noise.is_cuda and noise.dtype == torch.float32:
+            return ops.normal_(noise)      # Philox4x32-10 + Box-Muller kernel of libhpvg (stream follows torch.manual_seed)
         return noise.normal_(0, 1)
     elif type == 'benoulli':
         return noise.bernoulli_(0.5)

@@ -142,6 +142,15 @@ int hpvg_gp_bwd_f32(const float* gout, const float* g, float* dg, float lambda, 
  * optional fused noise injection yn = y + amp*noise (networks_3d.py:399-400).  BC = batch*channels. */
 int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, float amp, float* yn, long BC, int Ti, int Hi,
                                 int Wi, int To, int Ho, int Wo, void* stream);
+/* ---- N(0,1) noise (utils/images.py:49 zeros(..).normal_(0,1); networks_3d.py:32 reparameterisation eps): counter-based
+ * Philox4x32-10 + Box-Muller, stream = (seed, call_id, iter[0]); iter: device int bumped once per train iteration
+ * (hpvg_counter_inc_i32), so a replayed hipGraph draws fresh noise with unchanged launch arguments; NULL = 0. */
+int hpvg_normal_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream);
+/* resize + level noise generated in the kernel (networks_3d.py:395-400): y = resize(x), yn = y + amp * N(0,1) where the noise
+ * is exactly what hpvg_normal_f32 would write for the same stream; samples b < first_noisy get yn = y (C channels per sample). */
+int hpvg_upsample_linear_ac_noise_f32(const float* x, float* y, float* yn, float amp, long BC, int C, int first_noisy, int Ti, int Hi,
+                                      int Wi, int To, int Ho, int Wo, unsigned long long seed, unsigned call_id, const int* iter,
+                                      void* stream);
 /* backward: dx = resize^T(dy + dy2); dy2 (nullable) is the gradient of the noisy output yn.  A gather over the input
  * voxels in a fixed order: no float atomics, bitwise reproducible, dx need not be zeroed. */
 int hpvg_upsample_linear_ac_bwd_f32(const float* dy, const float* dy2, float* dx, long BC, int Ti, int Hi, int Wi, int To, int Ho,

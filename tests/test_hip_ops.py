@@ -591,3 +591,49 @@ def test_full_size_head_and_tail_convs_by_crops(ops, Cin, Cout):
                  slice(w0 - ws_, w0 - ws_ + w1 - w0))
         assert_close(y[0:1, :, t0:t1, h0:h1, w0:w1], O.conv(x[sl].cpu(), w.cpu(), b.cpu())[inner], RTOL, "crop.fwd")
         assert_close(dx[0:1, :, t0:t1, h0:h1, w0:w1], O.conv(dy[sl].cpu(), wf)[inner], RTOL, "crop.bwd_data")
+
+
+def test_device_noise_kernel(ops):
+    """hpvg_normal_f32 (Philox4x32-10 + Box-Muller): N(0,1) moments, no serial correlation, reproducible per
+    (seed, iteration, call), different across calls / iterations / seeds; and the resize kernel that generates the level
+    noise itself adds exactly that stream (networks_3d.py:395-400), to the rand half only when asked."""
+    import hp_vae_gan_amd.utils as hu
+    dev = torch.device(DEV)
+    torch.manual_seed(1234)
+    ops.rng_next_iteration(dev)
+    a = hu.generate_noise(size=[2, 3, 13, 144, 256], device=dev)          # 2.9 M values
+    x = a.double().flatten()
+    n = x.numel()
+    assert abs(float(x.mean())) < 4.0 / n ** 0.5
+    assert abs(float(x.var()) - 1.0) < 5.0 * (2.0 / n) ** 0.5
+    assert abs(float((x ** 3).mean())) < 5.0 * (15.0 / n) ** 0.5
+    assert abs(float((x ** 4).mean()) - 3.0) < 5.0 * (96.0 / n) ** 0.5
+    assert abs(float((x[:-1] * x[1:]).mean())) < 4.0 / n ** 0.5 and abs(float((x[:-4] * x[4:]).mean())) < 4.0 / n ** 0.5
+    assert float(x.abs().max()) < 7.0 and bool(torch.isfinite(x).all())
+    b = hu.generate_noise(ref=a)                                            # next call of the same iteration
+    assert abs(float((a.double() * b.double()).mean())) < 4.0 / n ** 0.5 and not torch.equal(a, b)
+    # same (seed, iteration, call) -> same stream; another iteration -> another stream
+    st = ops._rng(dev)
+    it0 = int(st.iter_dev.item())
+    st.call = 0
+    a2 = hu.generate_noise(ref=a)
+    assert torch.equal(a2, a)
+    ops.rng_next_iteration(dev)
+    assert int(st.iter_dev.item()) == it0 + 1 and st.call == 0
+    c = hu.generate_noise(ref=a)
+    assert not torch.equal(c, a) and abs(float((a.double() * c.double()).mean())) < 4.0 / n ** 0.5
+    torch.manual_seed(99)
+    st.call = 0
+    d = hu.generate_noise(ref=a)
+    assert not torch.equal(d, c)
+    # fused: resize + in-kernel noise == resize, then + amp * (the same stream written out)
+    xin = _rand(4, 3, 4, 18, 33, seed=7).to(DEV)
+    size = (4, 23, 41)
+    st.call = 5
+    up, upn = ops.UpsampleACNoise.apply(xin, size, 0.37, 2)
+    st.call = 5
+    nz = hu.generate_noise(ref=up)
+    plain = ops.UpsampleAC.apply(xin, size, None, 0.0)
+    assert torch.equal(up, plain)
+    assert torch.equal(upn[:2], plain[:2])                                  # the rec half of a merged pass gets no noise
+    assert_close(upn[2:], plain[2:] + 0.37 * nz[2:], 1e-6, "fused level noise")
