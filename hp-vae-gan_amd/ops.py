@@ -794,6 +794,8 @@ _rng_states = {}
 
 
 def _rng(device):
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())   # "cuda" and "cuda:0" are one stream
     key = (device.type, device.index)
     st = _rng_states.get(key)
     if st is None:

@@ -634,6 +634,6 @@ def test_device_noise_kernel(ops):
     st.call = 5
     nz = hu.generate_noise(ref=up)
     plain = ops.UpsampleAC.apply(xin, size, None, 0.0)
-    assert torch.equal(up, plain)
-    assert torch.equal(upn[:2], plain[:2])                                  # the rec half of a merged pass gets no noise
+    assert_close(up, plain, 1e-6, "fused resize")                          # (two kernels: fma contraction may differ in the last bit)
+    assert torch.equal(upn[:2], up[:2])                                     # the rec half of a merged pass gets no noise
     assert_close(upn[2:], plain[2:] + 0.37 * nz[2:], 1e-6, "fused level noise")
