@@ -62,6 +62,9 @@ struct ConvFwdArgs {
   const float* in_scale;
   const float* in_shift;
   const float* mask;  // optional [B][Cout][T][H][W]: y *= (mask > 0 ? 1 : 0.2) - leaky_relu_backward fused into the backward-data conv
+  // 1-bit form of such a mask, [B][T*H*W][ceil(Cout/32)] words (bit c%32 of word c/32 = activation > 0):
+  const unsigned* mask_bits;  // read by the masked epilogue INSTEAD of `mask` when given (8 loads per tile and lane, not 128)
+  unsigned* bits_out;         // written by a LeakyReLU epilogue for its consumer's backward-data conv
   float* y;
   int B, Cin, Cout, T, H, W;
   // tile = `L` consecutive positions of the row-flattened band (W split into ntw bands of Tw columns, LDS row stride
@@ -237,7 +240,7 @@ __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs
 // convs of the path - carries none of it (a run-time `if (a.mask)` in the epilogue alone cost the plain launches +1.6 % at
 // stage 9 through register allocation): 0 = plain, 1 = out_mask epilogue (leaky_relu_backward of the layer below),
 // 2 = the producer's BatchNorm-apply (+ LeakyReLU) fused into the staging (register path instead of LDS-DMA).
-constexpr int VAR_PLAIN = 0, VAR_MASK = 1, VAR_PRO = 2;
+constexpr int VAR_PLAIN = 0, VAR_MASK = 1, VAR_PRO = 2, VAR_BITS = 3;   // 3 = plain + bits_out (the activated forward convs)
 
 template <int CC, int KT, int MB, int NB, int VAR>
 __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(const ConvFwdArgs a) {
@@ -378,8 +381,30 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
       const int gh = Q / RS, ww = Q - gh * RS;
       const int gw = w0 + ww;
       const bool ok = q < a.L && ww < a.Tw && gh < a.H && gw < a.W;
-      if (!ok) continue;
       const long sp = (long)t * HW + (long)gh * a.W + gw;
+      const long wi = ((long)b * a.T * HW + sp) * a.mbtot + mb0;   // first mask word of this position
+      if constexpr (VAR == VAR_BITS) {
+        // (every lane takes part in the cross-half exchange below, so no early exit before it)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          unsigned word = 0;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float val = acc[m][i][e] + bias_r[m][e];      // sign(LeakyReLU(v)) = sign(v)
+            word |= (val > 0.f ? 1u : 0u) << ((e & 3) + 8 * (e >> 2) + 4 * half);
+          }
+          word |= (unsigned)__shfl_xor((int)word, 32, 64);      // the two half-waves hold complementary channels of one position
+          if (ok && half == 0 && (mb0 + m) * 32 < a.Cout) a.bits_out[wi + m] = word;
+        }
+      }
+      if (!ok) continue;
+      unsigned mword[MB];
+      if constexpr (VAR == VAR_MASK) {
+        if (a.mask_bits) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) mword[m] = (mb0 + m) * 32 < a.Cout ? a.mask_bits[wi + m] : 0u;
+        }
+      }
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -389,7 +414,10 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
             float val = acc[m][i][e] + bias_r[m][e];
             if (a.out_lrelu) val = hpvg_lrelu(val);
             const long oi = ((long)b * a.Cout + co) * a.T * HW + sp;
-            if constexpr (VAR == VAR_MASK) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+            if constexpr (VAR == VAR_MASK) {
+              if (a.mask_bits) val *= ((mword[m] >> ((e & 3) + 8 * (e >> 2) + 4 * half)) & 1u) ? 1.f : HPVG_LRELU_SLOPE;
+              else val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+            }
             a.y[oi] = val;
           }
         }
@@ -435,16 +463,27 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
     for (int e = 0; e < 16; ++e) v[e] += src[e * 256];
   }
   const long sp = (long)tc.t * HW + (long)gh * a.W + gw;
+  const long wi = ((long)tc.b * a.T * HW + sp) * a.mbtot + tc.mb0 + m;
+  const unsigned mword = a.mask_bits ? a.mask_bits[wi] : 0u;
+  unsigned word = 0;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int co = (tc.mb0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
     if (co >= a.Cout) continue;
     float val = v[e];
     if (a.bias) val += a.bias[co];
+    word |= (val > 0.f ? 1u : 0u) << ((e & 3) + 8 * (e >> 2) + 4 * half);
     if (a.out_lrelu) val = hpvg_lrelu(val);
     const long oi = ((long)tc.b * a.Cout + co) * a.T * HW + sp;
-    if (a.mask) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
+    if (a.mask_bits) val *= ((mword >> ((e & 3) + 8 * (e >> 2) + 4 * half)) & 1u) ? 1.f : HPVG_LRELU_SLOPE;
+    else if (a.mask) val *= a.mask[oi] > 0.f ? 1.f : HPVG_LRELU_SLOPE;
     a.y[oi] = val;
+  }
+  if (a.bits_out) {
+    // the partner half-wave holds the other 16 channels of this position; lanes that returned early above belong to
+    // positions outside the tile in BOTH halves (the test does not depend on `half`), so the exchange is well defined
+    word |= (unsigned)__shfl_xor((int)word, 32, 64);
+    if (half == 0) a.bits_out[wi] = word;
   }
 }
 
@@ -1084,7 +1123,8 @@ int launch_conv_var(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
 template <int CC, int KT, int MB, int NB>
 int launch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   if (a.in_scale) return launch_conv_var<CC, KT, MB, NB, VAR_PRO>(a, p, S, s);
-  if (a.mask) return launch_conv_var<CC, KT, MB, NB, VAR_MASK>(a, p, S, s);
+  if (a.mask || a.mask_bits) return launch_conv_var<CC, KT, MB, NB, VAR_MASK>(a, p, S, s);
+  if (a.bits_out) return launch_conv_var<CC, KT, MB, NB, VAR_BITS>(a, p, S, s);
   return launch_conv_var<CC, KT, MB, NB, VAR_PLAIN>(a, p, S, s);
 }
 
@@ -1195,9 +1235,34 @@ int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* 
 // the layer below, fused into this conv when it runs as that layer's consumer's backward-data pass.
 // ws / ws_bytes: hpvg_conv_fwd_ws_bytes() of scratch enables the stream-K schedule; with ws = NULL (or too small)
 // the same kernel runs one workgroup per tile.
+static int conv_fwd_impl(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
+                         int in_lrelu, float* y, int out_lrelu, const float* out_mask, const unsigned* mask_bits, unsigned* bits_out,
+                         void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT, void* stream);
+
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
                       int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
                       int Cout, int T, int H, int W, int KT, void* stream) {
+  return conv_fwd_impl(x, wp, bias, in_scale, in_shift, in_lrelu, y, out_lrelu, out_mask, nullptr, nullptr, ws, ws_bytes, B, Cin,
+                       Cout, T, H, W, KT, stream);
+}
+
+// number of 32-bit words of the 1-bit LeakyReLU mask of a [B][C][T][H][W] activation: [B][T*H*W][ceil(C/32)]
+size_t hpvg_conv_mask_words(int B, int C, int T, int H, int W) { return (size_t)B * T * H * W * hpvg_cdiv(C, 32); }
+
+// y = conv(x) (+bias) with the LeakyReLU sign mask in 1-bit form: `bits_out` (with out_lrelu; written for the consumer's
+// backward-data conv) and / or `mask_bits` (read instead of a float out_mask).  Cout > 4 only (the MFMA kernel).
+int hpvg_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, float* y, int out_lrelu, const unsigned* mask_bits,
+                           unsigned* bits_out, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT,
+                           void* stream) {
+  if (conv_is_narrow(Cin, Cout)) return HPVG_ERR_UNSUPPORTED;
+  if (mask_bits && bits_out) return HPVG_ERR_UNSUPPORTED;
+  return conv_fwd_impl(x, wp, bias, nullptr, nullptr, 0, y, out_lrelu, nullptr, mask_bits, bits_out, ws, ws_bytes, B, Cin, Cout, T, H,
+                       W, KT, stream);
+}
+
+static int conv_fwd_impl(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
+                         int in_lrelu, float* y, int out_lrelu, const float* out_mask, const unsigned* mask_bits, unsigned* bits_out,
+                         void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT, void* stream) {
   if (!x || !wp || !y) return HPVG_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
@@ -1218,6 +1283,7 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
   }
   ConvFwdArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.mask = out_mask; a.y = y;
+  a.mask_bits = mask_bits; a.bits_out = bits_out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.PL = p.PL; a.L = p.L; a.qstride = p.qstride; a.nrange = p.nrange; a.ntw = p.ntw; a.nblocks = p.nblocks;
   a.nchunk = nchunk;

@@ -32,6 +32,8 @@ _SIGS = {
     "hpvg_conv_pack_weight_batch_f32": [I, P, P, P, I, I, P],
     "hpvg_conv_fwd_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_fwd_f32": [P, P, P, P, P, I, P, I, P, P, Z, I, I, I, I, I, I, I, P],
+    "hpvg_conv_mask_words": [I, I, I, I, I],
+    "hpvg_conv_fwd_bits_f32": [P, P, P, P, I, P, P, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_fwd_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_narrow_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_ws_bytes": [I, I, I, I, I, I, I],
@@ -84,7 +86,7 @@ _SIGS = {
     "hpvg_counter_inc_i32": [P, P],
     "hpvg_graph_node_census": [P, P, I],
 }
-_SIZE_FUNCS = {"hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_conv_mask_words", "hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 
 
 def header_symbols():
@@ -135,7 +137,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise RuntimeError("hp-vae-gan_amd: tensor is on %s; these ops run only on an MI355X device (no CPU fallback)" % t.device)
-    if t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int32):
+    if t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int32):  # int32 also carries the 1-bit mask words
         raise RuntimeError("hp-vae-gan_amd: unsupported dtype %s" % t.dtype)
     if not t.is_contiguous():
         raise RuntimeError("hp-vae-gan_amd: tensor must be contiguous")

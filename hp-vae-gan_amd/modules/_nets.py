@@ -40,13 +40,13 @@ class Conv(nn.Module):
     # multi-GPU: slab.Halo when this layer's level is cut into row slabs over neighbouring ranks (multigpu.py sets it)
     halo = None
 
-    def forward(self, x, act=False, in_act=False):
+    def forward(self, x, act=False, in_act=False, in_bits=None):
         """in_act: x is the activated output of a spectral-norm block that left its LeakyReLU backward to this conv
-        (ops.Conv: the mask rides in this layer's backward-data epilogue)."""
+        (ops.Conv: the mask rides in this layer's backward-data epilogue); in_bits: its 1-bit form from the producer."""
         if self.halo is not None:
             assert self.padding == 1, "row slabs are implemented for the 'same' convolutions of the HP-VAE-GAN path"
             return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, self.weight, self.bias, act, in_act))
-        y = ops.Conv.apply(x, self.weight, self.bias, act, in_act)
+        y = ops.Conv.apply(x, self.weight, self.bias, act, in_act, False, in_bits if self.padding == 1 else None)
         return y if self.padding == 1 else crop_border(y)
 
 
@@ -86,14 +86,15 @@ class SNConv(nn.Module):
 
     halo = None  # as Conv.halo
 
-    def forward(self, x, act=False, weight=None, in_act=False, mask_by_consumer=False):
+    def forward(self, x, act=False, weight=None, in_act=False, mask_by_consumer=False, in_bits=None):
         """weight: the effective weight when the caller computed it for all of its spectral-norm layers at once
         (sn_weights below); None: this layer runs its own power iteration.  in_act / mask_by_consumer: see ops.Conv
-        (the LeakyReLU backward of a chain of activated convs rides in the consumer's backward-data epilogue)."""
+        (the LeakyReLU backward of a chain of activated convs rides in the consumer's backward-data epilogue).
+        Returns (y, bits): bits = the 1-bit mask of y for the consumer (None on row slabs or without mask_by_consumer)."""
         w = weight if weight is not None else self.effective_weight()
         if self.halo is not None:
-            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act, in_act, mask_by_consumer))
-        return ops.Conv.apply(x, w, self.bias, act, in_act, mask_by_consumer)
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act, in_act, mask_by_consumer)), None
+        return ops.Conv.apply_bits(x, w, self.bias, act, in_act, mask_by_consumer, in_bits)
 
 
 def sn_weights(convs):
@@ -177,10 +178,10 @@ class ConvBlock(nn.Module):
         self.has_bn = bn
         self.act = act
 
-    def forward(self, x, in_act=False):
+    def forward(self, x, in_act=False, in_bits=None):
         if self.has_bn:
-            return self.norm(self.conv(x, in_act=in_act), lrelu=self.act is not None)
-        return self.conv(x, act=self.act is not None, in_act=in_act)
+            return self.norm(self.conv(x, in_act=in_act, in_bits=in_bits), lrelu=self.act is not None)
+        return self.conv(x, act=self.act is not None, in_act=in_act, in_bits=in_bits)
 
 
 class ConvBlockSN(nn.Module):
@@ -196,9 +197,11 @@ class ConvBlockSN(nn.Module):
         self.conv = SNConv(dims, in_channel, out_channel, ker_size, padding, stride)
         self.act = act
 
-    def forward(self, x, weight=None, in_act=False, mask_by_consumer=False):
-        return self.conv(x, act=self.act is not None, weight=weight, in_act=in_act,
-                         mask_by_consumer=mask_by_consumer and self.act is not None)
+    def forward(self, x, weight=None, in_act=False, mask_by_consumer=False, in_bits=None, with_bits=False):
+        """with_bits: return (y, bits) - the 1-bit LeakyReLU mask for the conv that consumes y (see SNConv.forward)."""
+        y, bits = self.conv(x, act=self.act is not None, weight=weight, in_act=in_act,
+                            mask_by_consumer=mask_by_consumer and self.act is not None, in_bits=in_bits)
+        return (y, bits) if with_bits else y
 
 
 class FeatureExtractor(nn.Sequential):
@@ -218,9 +221,10 @@ class FeatureExtractor(nn.Sequential):
         logvar heads), so the last block leaves its LeakyReLU backward to them like the inner blocks do."""
         blocks = list(self)
         last = len(blocks) - 1
+        bits = None
         for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
-            x = blk(x, weight=w, in_act=i > 0, mask_by_consumer=(i < last or mask_by_consumer))
-        return x
+            x, bits = blk(x, weight=w, in_act=i > 0, mask_by_consumer=(i < last or mask_by_consumer), in_bits=bits, with_bits=True)
+        return (x, bits) if mask_by_consumer else x
 
 
 class EncodeVAE(nn.Module):
@@ -238,8 +242,8 @@ class EncodeVAE(nn.Module):
         self.logvar = ConvBlock(dims, opt.nfc, output_dim, opt.ker_size, opt.ker_size // 2, 1, bn=False, act=None)
 
     def forward(self, x):
-        features = self.features(x, mask_by_consumer=True)
-        return self.mu(features, in_act=True), self.logvar(features, in_act=True)
+        features, bits = self.features(x, mask_by_consumer=True)
+        return self.mu(features, in_act=True, in_bits=bits), self.logvar(features, in_act=True, in_bits=bits)
 
 
 def _seven_conv_stack(dims, in_channel, N, opt, padding):
@@ -270,9 +274,10 @@ class WDiscriminator(nn.Module):
         blocks = [self.head] + list(self.body)
         # every activation of the chain has exactly one consumer, the next conv: its LeakyReLU backward rides in that conv's
         # backward-data epilogue (ops.Conv in_act / mask_by_consumer) instead of being a pass of its own
+        bits = None
         for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
-            x = blk(x, weight=w, in_act=i > 0, mask_by_consumer=True)
-        return self.tail(x, in_act=True)
+            x, bits = blk(x, weight=w, in_act=i > 0, mask_by_consumer=True, in_bits=bits, with_bits=True)
+        return self.tail(x, in_act=True, in_bits=bits)
 
 
 class GeneratorHPVAEGAN(nn.Module):

@@ -157,9 +157,12 @@ def prepack_weights(ws, flips=(False, True)):
         _pack_cache[key] = (w._version, w.detach(), wp)
 
 
-def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False, out_mask=None):
+def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False, out_mask=None, mask_bits=None,
+                 want_bits=False):
     """y = conv(f(x), w) (+bias); flip=True runs the backward-data conv of the layer weight w.
-    out_mask (shaped like y): y *= (out_mask > 0 ? 1 : 0.2) in the kernel's epilogue (leaky_relu_backward of the layer below)."""
+    out_mask (shaped like y): y *= (out_mask > 0 ? 1 : 0.2) in the kernel's epilogue (leaky_relu_backward of the layer below);
+    mask_bits: the same mask in 1-bit form (int32 words, written by the producer of the activation: want_bits=True with
+    out_lrelu returns (y, bits))."""
     x = _c(x)
     B, C, T, H, W = geom(x)
     KT = _kt(w.shape)
@@ -181,13 +184,22 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     ws = workspace(nws, x.device) if nws else None
     if out_mask is not None and tuple(out_mask.shape) != tuple(shape):
         raise RuntimeError("conv: out_mask has shape %s, the output %s" % (tuple(out_mask.shape), tuple(shape)))
-    call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
-         1 if out_lrelu else 0, ptr(_c(out_mask)) if out_mask is not None else None, ptr(ws),
-         ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT, stream())
+    bits = None
+    if (mask_bits is not None or want_bits) and cout_k > 4 and in_affine is None:
+        if want_bits:
+            bits = torch.empty(call("hpvg_conv_mask_words", B, cout_k, T, H, W), dtype=torch.int32, device=x.device)
+        if mask_bits is not None and mask_bits.numel() != call("hpvg_conv_mask_words", B, cout_k, T, H, W):
+            raise RuntimeError("conv: mask_bits has %d words, the output needs %d" % (mask_bits.numel(), call("hpvg_conv_mask_words", B, cout_k, T, H, W)))
+        call("hpvg_conv_fwd_bits_f32", ptr(x), ptr(wp), ptr(bias), ptr(y), 1 if out_lrelu else 0, ptr(mask_bits), ptr(bits), ptr(ws),
+             ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT, stream())
+    else:
+        call("hpvg_conv_fwd_f32", ptr(x), ptr(wp), ptr(bias), ptr(sc), ptr(sh), 1 if in_lrelu else 0, ptr(y),
+             1 if out_lrelu else 0, ptr(_c(out_mask)) if out_mask is not None else None, ptr(ws),
+             ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT, stream())
     if timed is not None:
         timed[1].record()
         _kernel_timer.events.append(((B, cin_k, T, H, W), timed[0], timed[1]))
-    return y
+    return (y, bits) if want_bits else y
 
 
 _DIRECT_GRAD = os.environ.get("HPVG_DIRECT_GRAD", "1") != "0"
@@ -311,37 +323,58 @@ class Conv(Function):
       mask_by_consumer : (with act) every consumer of y is such a Conv, so this backward must NOT mask dy again."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, in_act=False, mask_by_consumer=False):
-        y = conv_fwd_raw(x, w, b, out_lrelu=act)
+    def forward(ctx, x, w, b, act, in_act=False, mask_by_consumer=False, in_bits=None):
+        """in_bits: the 1-bit LeakyReLU mask of x as its producer's epilogue wrote it (see Conv.apply_bits); the
+        backward-data epilogue then reads 1/32 of the bytes.  Without it (row slabs: x was extended by halo rows) the mask
+        is read from x itself."""
+        want = act and mask_by_consumer and w.shape[0] > 4
+        if want:
+            y, bits = conv_fwd_raw(x, w, b, out_lrelu=True, want_bits=True)
+            Conv.last_bits = bits          # handed to the caller by apply_bits (not an autograd output)
+        else:
+            y = conv_fwd_raw(x, w, b, out_lrelu=act)
+            Conv.last_bits = None
         own_mask = act and not mask_by_consumer
-        ctx.save_for_backward(x, w, y if own_mask else None, b)
+        ctx.save_for_backward(x, w, y if own_mask else None, b, in_bits if in_act else None)
         ctx.own_mask, ctx.in_act = own_mask, in_act
         ctx.has_bias = b is not None
         return y
 
+    last_bits = None
+
+    @staticmethod
+    def apply_bits(x, w, b, act, in_act=False, mask_by_consumer=False, in_bits=None):
+        """Conv.apply that also returns the 1-bit mask of the activated output (None when this call made none)."""
+        y = Conv.apply(x, w, b, act, in_act, mask_by_consumer, in_bits)
+        bits, Conv.last_bits = Conv.last_bits, None
+        return y, bits
+
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, b = ctx.saved_tensors
+        x, w, y, b, in_bits = ctx.saved_tensors
         dy = _c(dy)
         if ctx.own_mask:
             dy = LReLUMaskMul.apply(dy, y)
         params = not inputs_only.active
-        dx = ConvBwdData.apply(dy, w, x if ctx.in_act else None) if ctx.needs_input_grad[0] else None
+        dx = ConvBwdData.apply(dy, w, x if ctx.in_act else None, in_bits) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(dy, x, w) if (ctx.needs_input_grad[1] and params) else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and params:
             slot = grad_slot(b)
             db = channel_sum_raw(dy, into=slot) if slot is not None else ChannelSum.apply(dy)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class ConvBwdData(Function):
     """dx = conv(dy, flip/transpose(w)) [* lrelu'(h)]: backward-data of a stride-1 'same' conv; with h (the activated tensor
-    the conv consumed) the LeakyReLU backward of the layer below is applied in the kernel's epilogue."""
+    the conv consumed) the LeakyReLU backward of the layer below is applied in the kernel's epilogue - from the 1-bit mask
+    `bits` when the producer of h wrote one."""
 
     @staticmethod
-    def forward(ctx, dy, w, h=None):
+    def forward(ctx, dy, w, h=None, bits=None):
         ctx.save_for_backward(dy, w, h)
+        if h is not None and bits is not None and w.shape[1] > 4:
+            return conv_fwd_raw(dy, w, None, flip=True, mask_bits=bits)
         return conv_fwd_raw(dy, w, None, flip=True, out_mask=h)
 
     @staticmethod
@@ -352,7 +385,7 @@ class ConvBwdData(Function):
             g = LReLUMaskMul.apply(g, h)     # second order only (the gradient penalty's double backward): a pass of its own
         ddy = Conv.apply(g, w, None, False) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(dy, g, w) if ctx.needs_input_grad[1] else None
-        return ddy, dw, None
+        return ddy, dw, None, None
 
 
 class ConvBwdWeight(Function):

@@ -51,6 +51,14 @@ size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
                       int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
                       int Cout, int T, int H, int W, int KT, void* stream);
+/* The same conv with the LeakyReLU sign mask in 1-BIT form ([B][T*H*W][ceil(C/32)] words, bit c%32 of word c/32 = activation
+ * of channel c > 0; hpvg_conv_mask_words() of them): `bits_out` (nullable) is written by an out_lrelu epilogue for the
+ * backward-data conv of the layer that consumes the activation, which passes it as `mask_bits` (nullable; instead of the
+ * fp32 `out_mask` of hpvg_conv_fwd_f32: 8 mask loads per tile and lane instead of 128).  Cout > 4 only. */
+size_t hpvg_conv_mask_words(int B, int C, int T, int H, int W);
+int hpvg_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, float* y, int out_lrelu, const unsigned* mask_bits,
+                           unsigned* bits_out, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT,
+                           void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
 /* host only: tile plan of the narrow-output kernel (Cout <= 4): out[0..6] = RS, Th, nth, nb, npos, G, pitch, then nb triples
  * (window start, first output column, output columns); out needs 7 + 3*16 ints */

@@ -8,7 +8,7 @@ from torch.profiler import profile, ProfilerActivity
 bench.CONFIG = sys.argv[1] if len(sys.argv) > 1 else "video"
 stage = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 built, shapes = bench.build_gpu_stages(torch.device("cuda", 0), [stage])
-s, tr, real, rz = built[0]
+s, tr, _step, real, rz = built[0]
 for _ in range(3):
     tr.step(real, rz)
 torch.cuda.synchronize()

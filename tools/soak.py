@@ -13,7 +13,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 stages = [int(a) for a in sys.argv[3:]] or [2, 4, 6]
 built, shapes = bench.build_gpu_stages(torch.device("cuda", 0), stages)
-for s, tr, real, rz in built:
+for s, tr, _step, real, rz in built:
     tr.step(real, rz)
     tr.step(real, rz)
     if mode == "graph":
