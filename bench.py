@@ -350,7 +350,9 @@ def main():
     barrier()
     # ---- timed region: exactly K steps; the dominant kernel's launches are bracketed by HIP events on the launch stream
     KT = 1 if CONFIG == "image" else 3
-    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == KT and not g["flip"])
+    # the plain template instance (what `rocprofv3 --stats` lists as conv_mfma_kernel<8, 3, 2, 4, 0>): forward convs of the
+    # generator blocks; the critic's activated convs run the bit-mask-writing variant and are not mixed into the figure
+    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == KT and not g["flip"] and g["var"] == "plain")
     ops.set_kernel_timer(timer)
     stage_ev = {}
     import gc

@@ -652,6 +652,20 @@ __global__ __launch_bounds__(256) void normal_kernel(float* __restrict__ out, lo
   }
 }
 
+// U(0,1) from the same Philox stream (reparameterize_bern's eps, networks_3d.py:40)
+__global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned call_id,
+                                                       const int* __restrict__ iter) {
+  const unsigned it = iter ? (unsigned)iter[0] : 0u;
+  const long nq = (n + 3) / 4;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    const Philox4 r = philox4x32_10((unsigned)q, (unsigned)((unsigned long long)q >> 32), call_id, it, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < n) out[4 * q + e] = (float)(w[e] >> 8) * (1.f / 16777216.f);   // [0, 1) like Tensor.uniform_()
+  }
+}
+
 // ------------------------------------------------------------------ tri/bi-linear resize, align_corners=True
 // utils/images.py:13,17,24 (F.interpolate(..., align_corners=True)).  src = dst*(in-1)/(out-1) in fp32.
 struct Lin { int i0, i1; float w0, w1; };
@@ -1430,6 +1444,11 @@ int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, fl
 int hpvg_normal_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream) {
   if (!out || n < 1) return HPVG_ERR_ARG;
   hipLaunchKernelGGL(normal_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, call_id, iter);
+  return hpvg_launch_status();
+}
+int hpvg_uniform_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream) {
+  if (!out || n < 1) return HPVG_ERR_ARG;
+  hipLaunchKernelGGL(uniform_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, call_id, iter);
   return hpvg_launch_status();
 }
 // y = resize(x); yn = y + amp * N(0,1) with the noise of hpvg_normal_f32(stream (seed, call_id, iter)) generated in the kernel;

@@ -72,6 +72,7 @@ _SIGS = {
     "hpvg_gp_bwd_f32": [P, P, P, F, I, I, L, P],
     "hpvg_upsample_linear_ac_f32": [P, P, P, F, P, L, I, I, I, I, I, I, P],
     "hpvg_normal_f32": [P, L, ctypes.c_ulonglong, ctypes.c_uint, P, P],
+    "hpvg_uniform_f32": [P, L, ctypes.c_ulonglong, ctypes.c_uint, P, P],
     "hpvg_upsample_linear_ac_noise_f32": [P, P, P, F, L, I, I, I, I, I, I, I, I, ctypes.c_ulonglong, ctypes.c_uint, P, P],
     "hpvg_frames_resize_norm_u8_f32": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "hpvg_upsample_linear_ac_bwd_f32": [P, P, P, L, I, I, I, I, I, I, P],
@@ -85,6 +86,15 @@ _SIGS = {
     "hpvg_adam_step_f32": [P, P, P, P, L, F, F, F, F, I, P, P],
     "hpvg_counter_inc_i32": [P, P],
     "hpvg_graph_node_census": [P, P, I],
+    "hpvg_gate_fwd_f32": [P, P, P, P, I, I, L, P],
+    "hpvg_gate_bwd_f32": [P, P, P, P, P, P, I, I, L, P],
+    "hpvg_rowsum_f32": [P, P, P, F, I, I, L, P],
+    "hpvg_outer_f32": [P, P, P, F, I, I, L, P],
+    "hpvg_colsum_f32": [P, P, P, I, I, L, P],
+    "hpvg_reparam_bern_fwd_f32": [P, P, P, L, P],
+    "hpvg_reparam_bern_bwd_f32": [P, P, P, L, P],
+    "hpvg_kl_bern_fwd_f32": [P, P, P, Z, L, P],
+    "hpvg_kl_bern_bwd_f32": [P, P, P, L, P],
 }
 _SIZE_FUNCS = {"hpvg_conv_mask_words", "hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 

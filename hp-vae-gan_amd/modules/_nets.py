@@ -26,14 +26,16 @@ class Conv(nn.Module):
 
     def __init__(self, dims, in_channel, out_channel, ker_size=3, padding=1, stride=1):
         super().__init__()
-        if ker_size != 3 or padding not in (0, 1) or stride != 1:
-            raise NotImplementedError("the MI355X path implements ker_size=3, padding in {0, 1}, stride=1")
+        if stride != 1 or not ((ker_size == 3 and padding in (0, 1)) or (ker_size == 1 and padding == 0)):
+            raise NotImplementedError("the MI355X path implements ker_size=3 with padding in {0, 1} and ker_size=1 with padding 0, stride=1")
         self.dims = dims
-        self.padding = padding
-        self.weight = nn.Parameter(torch.empty(out_channel, in_channel, *_kernel_shape(dims)))
+        self.ker_size = ker_size
+        # a 1x1(x1) convolution (Encode3DVAE1x1, networks_3d.py:141-160) = the 3x3(x3) 'same' conv of its centre-embedded weight
+        self.padding = padding if ker_size == 3 else 1
+        self.weight = nn.Parameter(torch.empty(out_channel, in_channel, *((ker_size,) * dims)))
         self.bias = nn.Parameter(torch.empty(out_channel))
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        fan_in = in_channel * 3 ** dims
+        fan_in = in_channel * ker_size ** dims
         bound = 1 / math.sqrt(fan_in)
         init.uniform_(self.bias, -bound, bound)
 
@@ -43,11 +45,17 @@ class Conv(nn.Module):
     def forward(self, x, act=False, in_act=False, in_bits=None):
         """in_act: x is the activated output of a spectral-norm block that left its LeakyReLU backward to this conv
         (ops.Conv: the mask rides in this layer's backward-data epilogue); in_bits: its 1-bit form from the producer."""
+        w = self.weight if self.ker_size == 3 else embed_center(self.weight, self.dims)
         if self.halo is not None:
             assert self.padding == 1, "row slabs are implemented for the 'same' convolutions of the HP-VAE-GAN path"
-            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, self.weight, self.bias, act, in_act))
-        y = ops.Conv.apply(x, self.weight, self.bias, act, in_act, False, in_bits if self.padding == 1 else None)
+            return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act, in_act))
+        y = ops.Conv.apply(x, w, self.bias, act, in_act, False, in_bits if self.padding == 1 else None)
         return y if self.padding == 1 else crop_border(y)
+
+
+def embed_center(w, dims):
+    """[Co, Ci, 1, 1(, 1)] -> [Co, Ci, 3, 3(, 3)], zero except the centre tap (data movement; its backward is the slice)."""
+    return torch.nn.functional.pad(w, (1, 1) * dims)
 
 
 def crop_border(y):
@@ -64,13 +72,14 @@ class SNConv(nn.Module):
 
     def __init__(self, dims, in_channel, out_channel, ker_size=3, padding=1, stride=1):
         super().__init__()
-        if ker_size != 3 or padding != 1 or stride != 1:
-            raise NotImplementedError("the MI355X path implements ker_size=3, padding=1, stride=1 (reference defaults)")
+        if stride != 1 or not ((ker_size == 3 and padding == 1) or (ker_size == 1 and padding == 0)):
+            raise NotImplementedError("the MI355X path implements ker_size=3 / padding=1 (reference defaults) and ker_size=1 / padding=0, stride=1")
         self.dims = dims
-        weight = torch.empty(out_channel, in_channel, *_kernel_shape(dims))
+        self.ker_size = ker_size
+        weight = torch.empty(out_channel, in_channel, *((ker_size,) * dims))
         init.kaiming_uniform_(weight, a=math.sqrt(5))
         bias = torch.empty(out_channel)
-        fan_in = in_channel * 3 ** dims
+        fan_in = in_channel * ker_size ** dims
         bound = 1 / math.sqrt(fan_in)
         init.uniform_(bias, -bound, bound)
         self.bias = nn.Parameter(bias)
@@ -92,6 +101,8 @@ class SNConv(nn.Module):
         (the LeakyReLU backward of a chain of activated convs rides in the consumer's backward-data epilogue).
         Returns (y, bits): bits = the 1-bit mask of y for the consumer (None on row slabs or without mask_by_consumer)."""
         w = weight if weight is not None else self.effective_weight()
+        if self.ker_size == 1:
+            w = embed_center(w, self.dims)
         if self.halo is not None:
             return conv_with_halo(x, self.halo, lambda xe: ops.Conv.apply(xe, w, self.bias, act, in_act, mask_by_consumer)), None
         return ops.Conv.apply_bits(x, w, self.bias, act, in_act, mask_by_consumer, in_bits)
@@ -107,7 +118,8 @@ def sn_weights(convs):
         for m in part:
             args += [m.weight_orig, m.weight_u, m.weight_v]
         out += list(ops.SpectralNormWeightBatch.apply(part[0].training, 1e-12, *args))
-    ops.prepack_weights(out)   # forward and backward-data packs of the equal-shaped layers: one launch
+    if all(tuple(w.shape[2:]) == (3,) * (w.dim() - 2) for w in out):
+        ops.prepack_weights(out)   # forward and backward-data packs of the equal-shaped layers: one launch
     return out
 
 
@@ -382,12 +394,20 @@ class GeneratorHPVAEGAN(nn.Module):
             return hp_utils.images.level_shape_3d(index, self.opt)
         return hp_utils.images.level_shape_2d(index, self.opt)
 
+    def _detach_before(self, idx):
+        """does the reference cut the graph in front of body[idx]?  (networks_3d.py:391-392)"""
+        return self.opt.vae_levels == idx + 1 and not self.opt.train_all
+
+    def _inject_noise(self, idx, mode):
+        """does body[idx] get level noise?  3-D: only from the first GAN level on (networks_3d.py:398); 2-D: every level"""
+        return mode == 'rand' and (self.dims == 2 or self.opt.vae_levels <= idx + 1)
+
     def refinement_layers(self, start_idx, x_prev_out, noise_amp, mode, stop_idx=None):
         for idx, block in enumerate(self.body[start_idx:stop_idx], start_idx):
-            if self.opt.vae_levels == idx + 1 and not self.opt.train_all:
+            if self._detach_before(idx):
                 x_prev_out.detach_()
             size = self._level_size(idx + 1)
-            inject = mode == 'rand' and (self.dims == 2 or self.opt.vae_levels <= idx + 1)
+            inject = self._inject_noise(idx, mode)
             if inject and self.noise_source is None:
                 up, up_noisy = ops.UpsampleACNoise.apply(x_prev_out, tuple(size), float(noise_amp[idx + 1]), 0)   # noise made in the kernel
             elif inject:
@@ -407,6 +427,107 @@ class GeneratorHPVAEGAN(nn.Module):
             if slab is not None and idx + 1 < len(self.body):
                 x_prev_out = slab.gather(x_prev_out, size[-2])
         return x_prev_out
+
+
+class _GlobalAvgPool(nn.Module):
+    """nn.AdaptiveAvgPool3d(1) / nn.AdaptiveAvgPool2d(1) (no parameters; keeps the reference's Sequential numbering)."""
+
+    def forward(self, x):
+        return ops.GlobalAvgPool.apply(x)
+
+
+class EncodeVAE_nb(nn.Module):
+    """Encode3DVAE_nb / Encode2DVAE_nb (reference: networks_3d.py:110-138, networks_2d.py:115-143): features gated by a
+    sigmoid map `bern`, then mu / logvar convs followed by GLOBAL average pooling ([B, latent, 1, 1, 1] codes)."""
+
+    def __init__(self, dims, opt, out_dim=None, num_blocks=2):
+        super().__init__()
+        if out_dim is None:
+            output_dim = opt.nfc
+        else:
+            assert type(out_dim) is int
+            output_dim = out_dim
+        k, p = opt.ker_size, opt.ker_size // 2
+        self.features = FeatureExtractor(dims, opt.nc_im, opt.nfc, k, p, 1, num_blocks=num_blocks)
+        self.mu = nn.Sequential(ConvBlock(dims, opt.nfc, output_dim, k, p, 1, bn=False, act=None), _GlobalAvgPool())
+        self.logvar = nn.Sequential(ConvBlock(dims, opt.nfc, output_dim, k, p, 1, bn=False, act=None), _GlobalAvgPool())
+        self.bern = ConvBlock(dims, opt.nfc, 1, k, p, 1, bn=False, act=None)
+
+    def forward(self, x):
+        features = self.features(x)
+        features, bern = ops.Gate.apply(features, self.bern(features))     # bern = sigmoid(conv), features *= bern
+        return self.mu(features), self.logvar(features), bern
+
+
+class EncodeVAE1x1(nn.Module):
+    """Encode3DVAE1x1 (reference: networks_3d.py:141-160, networks_2d.py:146-165; instantiated by nothing in the reference):
+    the encoder with 1x1(x1) kernels - run as centre-embedded 3x3(x3) convs."""
+
+    def __init__(self, dims, opt, out_dim=None):
+        super().__init__()
+        if out_dim is None:
+            output_dim = opt.nfc
+        else:
+            assert type(out_dim) is int
+            output_dim = out_dim
+        self.features = FeatureExtractor(dims, opt.nc_im, opt.nfc, 1, 0, 1, num_blocks=2)
+        self.mu = ConvBlock(dims, opt.nfc, output_dim, 1, 0, 1, bn=False, act=None)
+        self.logvar = ConvBlock(dims, opt.nfc, output_dim, 1, 0, 1, bn=False, act=None)
+
+    def forward(self, x):
+        features = self.features(x)
+        return self.mu(features), self.logvar(features)
+
+
+class GeneratorVAE_nb(GeneratorHPVAEGAN):
+    """GeneratorVAE_nb (reference: networks_3d.py:409-485, networks_2d.py:272-348): the HP-VAE-GAN generator with the
+    normal x relaxed-Bernoulli latent of EncodeVAE_nb.  Differences to GeneratorHPVAEGAN kept exactly: forward takes
+    (noise_init_norm, noise_init_bern) and returns (mu, logvar, bern); the decoder input is code [B, C, 1, ..] x map
+    [B, 1, ...]; the refinement detaches at vae_levels regardless of train_all and injects noise at EVERY level in 'rand' mode.
+    No trainer of the reference can drive it (train_video.py:140 unpacks two statistics)."""
+
+    def __init__(self, dims, opt):
+        super().__init__(dims, opt)
+        self.encode = EncodeVAE_nb(dims, opt, out_dim=opt.latent_dim, num_blocks=opt.enc_blocks)
+
+    def _detach_before(self, idx):
+        return self.opt.vae_levels == idx + 1
+
+    def _inject_noise(self, idx, mode):
+        return mode == 'rand'
+
+    def _uniform_like(self, ref):
+        if self.noise_source is not None:
+            return self.noise_source(ref)
+        return ops.uniform_(torch.empty_like(ref))
+
+    def _reparameterize_bern(self, x):
+        """reference: networks_3d.py:38-45"""
+        if self.training:
+            return ops.ReparamBern.apply(x, self._uniform_like(x))
+        return (self._uniform_like(x) < 0.5).to(x.dtype)      # zeros_like(x).bernoulli_(): p = 0.5
+
+    def forward(self, video, noise_amp, noise_init_norm=None, noise_init_bern=None, sample_init=None, mode='rand'):
+        if sample_init is not None:
+            assert len(self.body) > sample_init[0], "Strating index must be lower than # of body blocks"
+        if noise_init_norm is None:
+            mu, logvar, bern = self.encode(video)
+            z_vae_norm = self._reparameterize(mu, logvar)
+            z_vae_bern = self._reparameterize_bern(bern)
+        else:
+            z_vae_norm = noise_init_norm
+            z_vae_bern = noise_init_bern
+        vae_out = ops.TanhRes.apply(self.decoder(ops.CodeTimesMap.apply(z_vae_norm, z_vae_bern)), None)
+        if sample_init is not None:
+            x_prev_out = self.refinement_layers(sample_init[0], sample_init[1], noise_amp, mode)
+        else:
+            x_prev_out = self.refinement_layers(0, vae_out, noise_amp, mode)
+        if noise_init_norm is None:
+            return x_prev_out, vae_out, (mu, logvar, bern)
+        return x_prev_out, vae_out
+
+    def forward_pair(self, *a, **k):
+        raise NotImplementedError("the merged rec + rand pass is built for GeneratorHPVAEGAN")
 
 
 def weights_init(m):

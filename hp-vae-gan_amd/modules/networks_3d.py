@@ -4,7 +4,8 @@ from . import _nets
 from .. import ops
 
 __all__ = ['ConvBlock3D', 'ConvBlock3DSN', 'FeatureExtractor', 'Encode3DVAE', 'WDiscriminator3D', 'GeneratorHPVAEGAN',
-           'GeneratorSG', 'GeneratorCSG', 'WDiscriminatorBaselines', 'weights_init', 'reparameterize']
+           'GeneratorSG', 'GeneratorCSG', 'WDiscriminatorBaselines', 'weights_init', 'reparameterize', 'reparameterize_bern',
+           'Encode3DVAE_nb', 'Encode3DVAE1x1', 'GeneratorVAE_nb']
 
 weights_init = _nets.weights_init
 
@@ -58,3 +59,26 @@ class GeneratorCSG(_nets.GeneratorCSG):
 
 class WDiscriminatorBaselines(_nets.WDiscriminatorBaselines):
     """The baselines' BatchNorm critic on a zero-padded volume (reference: networks_3d.py:184-210)."""
+
+
+def reparameterize_bern(x, training, eps=None):
+    """log(x+1e-20) - log(-log(eps+1e-20)+1e-20), eps ~ U(0,1) when training; Bernoulli(0.5) otherwise (networks_3d.py:38-45)."""
+    import torch
+    if eps is None:
+        eps = ops.uniform_(torch.empty_like(x))
+    return ops.ReparamBern.apply(x, eps) if training else (eps < 0.5).to(x.dtype)
+
+
+class Encode3DVAE_nb(_nets.EncodeVAE_nb):
+    def __init__(self, opt, out_dim=None, num_blocks=2):
+        super().__init__(3, opt, out_dim=out_dim, num_blocks=num_blocks)
+
+
+class Encode3DVAE1x1(_nets.EncodeVAE1x1):
+    def __init__(self, opt, out_dim=None):
+        super().__init__(3, opt, out_dim=out_dim)
+
+
+class GeneratorVAE_nb(_nets.GeneratorVAE_nb):
+    def __init__(self, opt):
+        super().__init__(3, opt)

@@ -177,7 +177,8 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     if in_affine is not None:
         sc, sh = in_affine
     timed = None
-    if _kernel_timer is not None and _kernel_timer.match({"Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip}):
+    var = "pro" if in_affine is not None else ("mask" if (out_mask is not None or mask_bits is not None) else ("bits" if want_bits else "plain"))
+    if _kernel_timer is not None and _kernel_timer.match({"Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip, "var": var}):
         timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         timed[0].record()
     nws = call("hpvg_conv_fwd_ws_bytes", B, cin_k, cout_k, T, H, W, KT)
@@ -853,6 +854,144 @@ def normal_(out):
     call("hpvg_normal_f32", ptr(out), ctypes.c_long(out.numel()), _seed(), ctypes.c_uint(st.call & 0xFFFFFFFF), ptr(st.iter_dev), stream())
     st.call += 1
     return out
+
+
+def uniform_(out):
+    """out <- U[0, 1) from the library's Philox stream (reparameterize_bern's eps, networks_3d.py:40)."""
+    st = _rng(out.device)
+    call("hpvg_uniform_f32", ptr(out), ctypes.c_long(out.numel()), _seed(), ctypes.c_uint(st.call & 0xFFFFFFFF), ptr(st.iter_dev), stream())
+    st.call += 1
+    return out
+
+
+# ------------------------------------------------------------------------------------------ variant models (the _nb family)
+def _bcs(x):
+    B, C = x.shape[0], x.shape[1]
+    S = 1
+    for d in x.shape[2:]:
+        S *= int(d)
+    return B, C, S
+
+
+class Gate(Function):
+    """(bern * f, bern) with bern = sigmoid(logit) broadcast over channels (Encode3DVAE_nb: networks_3d.py:131-133)."""
+
+    @staticmethod
+    def forward(ctx, f, logit):
+        f, logit = _c(f), _c(logit)
+        B, C, S = _bcs(f)
+        out = torch.empty_like(f)
+        bern = torch.empty_like(logit)
+        call("hpvg_gate_fwd_f32", ptr(f), ptr(logit), ptr(out), ptr(bern), B, C, ctypes.c_long(S), stream())
+        ctx.save_for_backward(f, bern)
+        return out, bern
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, dbern):
+        f, bern = ctx.saved_tensors
+        B, C, S = _bcs(f)
+        dout = _c(dout) if dout is not None else None
+        dbern = _c(dbern) if dbern is not None else None
+        df = torch.empty_like(f) if (ctx.needs_input_grad[0] and dout is not None) else None
+        dlogit = torch.empty_like(bern) if ctx.needs_input_grad[1] else None
+        call("hpvg_gate_bwd_f32", ptr(dout), ptr(f), ptr(bern), ptr(dbern), ptr(df), ptr(dlogit), B, C, ctypes.c_long(S), stream())
+        return df, dlogit
+
+
+class GlobalAvgPool(Function):
+    """nn.AdaptiveAvgPool3d(1) / AdaptiveAvgPool2d(1): [B, C, ...] -> [B, C, 1, (1,) 1] (networks_3d.py:121-128)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, C, S = _bcs(x)
+        out = torch.empty((B, C) + (1,) * (x.dim() - 2), dtype=torch.float32, device=x.device)
+        call("hpvg_rowsum_f32", ptr(x), None, ptr(out), float(1.0 / S), B, C, ctypes.c_long(S), stream())
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g)
+        B, C, S = _bcs(torch.empty(ctx.shape, device="meta"))
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        call("hpvg_outer_f32", ptr(g), None, ptr(dx), float(1.0 / S), B, C, ctypes.c_long(S), stream())
+        return dx
+
+
+class CodeTimesMap(Function):
+    """z[b,c,s] = code[b,c] * map[b,s]: z_vae_norm [B,C,1,1,1] x z_vae_bern [B,1,T,H,W] (networks_3d.py:456)."""
+
+    @staticmethod
+    def forward(ctx, code, zmap):
+        code, zmap = _c(code), _c(zmap)
+        B, C = code.shape[0], code.shape[1]
+        S = zmap.numel() // B
+        if code.numel() != B * C or zmap.shape[1] != 1:
+            raise RuntimeError("CodeTimesMap: expected a [B,C,1,..] code and a [B,1,...] map, got %s, %s" % (tuple(code.shape), tuple(zmap.shape)))
+        out = torch.empty((B, C) + tuple(zmap.shape[2:]), dtype=torch.float32, device=code.device)
+        call("hpvg_outer_f32", ptr(code), ptr(zmap), ptr(out), 1.0, B, C, ctypes.c_long(S), stream())
+        ctx.save_for_backward(code, zmap)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        code, zmap = ctx.saved_tensors
+        dz = _c(dz)
+        B, C = code.shape[0], code.shape[1]
+        S = zmap.numel() // B
+        dcode = dmap = None
+        if ctx.needs_input_grad[0]:
+            dcode = torch.empty_like(code)
+            call("hpvg_rowsum_f32", ptr(dz), ptr(zmap), ptr(dcode), 1.0, B, C, ctypes.c_long(S), stream())
+        if ctx.needs_input_grad[1]:
+            dmap = torch.empty_like(zmap)
+            call("hpvg_colsum_f32", ptr(dz), ptr(code), ptr(dmap), B, C, ctypes.c_long(S), stream())
+        return dcode, dmap
+
+
+class ReparamBern(Function):
+    """log(x + 1e-20) - log(-log(eps + 1e-20) + 1e-20), eps ~ U(0,1) (reparameterize_bern, networks_3d.py:38-42)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x, eps = _c(x), _c(eps)
+        z = torch.empty_like(x)
+        call("hpvg_reparam_bern_fwd_f32", ptr(x), ptr(eps), ptr(z), ctypes.c_long(x.numel()), stream())
+        ctx.save_for_backward(x)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("hpvg_reparam_bern_bwd_f32", ptr(_c(dz)), ptr(x), ptr(dx), ctypes.c_long(x.numel()), stream())
+        return dx, None
+
+
+class KLBern(Function):
+    """mean(x (log(x+1e-20) - log .5) + (1-x)(log(1-x+1e-20) - log .5))  (kl_bern_criterion, modules/losses.py:12-14)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        out = _scalar_out(x.device)
+        ws, n = _reduce_ws(x.device)
+        call("hpvg_kl_bern_fwd_f32", ptr(x), ptr(out), ptr(ws), ctypes.c_size_t(n), ctypes.c_long(x.numel()), stream())
+        ctx.save_for_backward(x)
+        return out.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("hpvg_kl_bern_bwd_f32", ptr(_c(g).view(1)), ptr(x), ptr(dx), ctypes.c_long(x.numel()), stream())
+        return dx
 
 
 class UpsampleACNoise(Function):

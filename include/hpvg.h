@@ -154,6 +154,7 @@ int hpvg_upsample_linear_ac_f32(const float* x, float* y, const float* noise, fl
  * Philox4x32-10 + Box-Muller, stream = (seed, call_id, iter[0]); iter: device int bumped once per train iteration
  * (hpvg_counter_inc_i32), so a replayed hipGraph draws fresh noise with unchanged launch arguments; NULL = 0. */
 int hpvg_normal_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream);
+int hpvg_uniform_f32(float* out, long n, unsigned long long seed, unsigned call_id, const int* iter, void* stream); /* U[0,1) */
 /* resize + level noise generated in the kernel (networks_3d.py:395-400): y = resize(x), yn = y + amp * N(0,1) where the noise
  * is exactly what hpvg_normal_f32 would write for the same stream; samples b < first_noisy get yn = y (C channels per sample). */
 int hpvg_upsample_linear_ac_noise_f32(const float* x, float* y, float* yn, float amp, long BC, int C, int first_noisy, int Ti, int Hi,
@@ -199,6 +200,25 @@ int hpvg_clip_scale_f32(float* g, long n, const float* sqsum, float max_norm, fl
 int hpvg_adam_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                        int step, const int* step_dev, void* stream);
 int hpvg_counter_inc_i32(int* counter, void* stream);
+
+/* ---- variant models (no trainer of the reference drives them; module-surface completeness): Encode3DVAE_nb / Encode2DVAE_nb
+ * (networks_3d.py:110-138, networks_2d.py:115-143), GeneratorVAE_nb (networks_3d.py:409-485), reparameterize_bern
+ * (networks_3d.py:38-45), kl_bern_criterion (losses.py:12-14).  Tensors [B][C][S], S = T*H*W. */
+/* bern[b][s] = sigmoid(logit[b][s]); out = bern * f (broadcast over channels); backward: df, dlogit from dout and the gradient
+ * arriving at bern itself (either may be NULL) */
+int hpvg_gate_fwd_f32(const float* f, const float* logit, float* out, float* bern, int B, int C, long S, void* stream);
+int hpvg_gate_bwd_f32(const float* dout, const float* f, const float* bern, const float* dbern_ext, float* df, float* dlogit, int B,
+                      int C, long S, void* stream);
+/* out[b][c] = scale * sum_s x[b][c][s] * (w ? w[b][s] : 1): nn.AdaptiveAvgPool3d(1) with scale = 1/S, and d(outer)/d(code) */
+int hpvg_rowsum_f32(const float* x, const float* w, float* out, float scale, int B, int C, long S, void* stream);
+/* out[b][c][s] = g[b][c] * (w ? w[b][s] : scale): code x map (z_vae_norm * z_vae_bern) and the average pool's backward */
+int hpvg_outer_f32(const float* g, const float* w, float* out, float scale, int B, int C, long S, void* stream);
+/* out[b][s] = sum_c a[b][c][s] * v[b][c]: d(outer)/d(map) */
+int hpvg_colsum_f32(const float* a, const float* v, float* out, int B, int C, long S, void* stream);
+int hpvg_reparam_bern_fwd_f32(const float* x, const float* eps, float* z, long n, void* stream);
+int hpvg_reparam_bern_bwd_f32(const float* dz, const float* x, float* dx, long n, void* stream);
+int hpvg_kl_bern_fwd_f32(const float* x, float* out, void* ws, size_t ws_bytes, long n, void* stream);
+int hpvg_kl_bern_bwd_f32(const float* gout, const float* x, float* dx, long n, void* stream);
 
 /* ---- hipGraph replay of the iteration (host only): node census of a captured graph, counts[t] per hipGraphNodeType t
  * (0 kernel, 1 memcpy, 2 memset, ...; child graphs included).  The trainers refuse a captured iteration that holds

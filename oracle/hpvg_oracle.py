@@ -376,6 +376,69 @@ def generator_forward(P, opt, dims, video, noise_amp, noise_init=None, mode='ran
     return x, vae_out
 
 
+# ----------------------------------------------------------------------------------------------- variant models
+def encoder_nb_forward(x, P, opt, training=True):
+    """Encode3DVAE_nb / Encode2DVAE_nb.forward (networks_3d.py:130-138, networks_2d.py:135-143): features gated by
+    bern = sigmoid(conv), then mu / logvar = global average of a conv.  Keys: encode.features.*, encode.{mu,logvar}.0.conv.*,
+    encode.bern.conv.*"""
+    h = x
+    for i in range(opt.enc_blocks + 1):
+        h = _sn_block(h, P, 'encode.features.conv_block_%d' % i, training)
+    bern = torch.sigmoid(conv(h, P['encode.bern.conv.weight'], P['encode.bern.conv.bias']))
+    h = bern * h
+    dims = tuple(range(2, x.dim()))
+    mu = conv(h, P['encode.mu.0.conv.weight'], P['encode.mu.0.conv.bias']).mean(dim=dims, keepdim=True)
+    logvar = conv(h, P['encode.logvar.0.conv.weight'], P['encode.logvar.0.conv.bias']).mean(dim=dims, keepdim=True)
+    return mu, logvar, bern
+
+
+def conv1x1(x, w, b=None):
+    """kernel-size-1 convolution (Encode3DVAE1x1, networks_3d.py:141-160): a per-voxel matrix product."""
+    y = torch.einsum('oc,bc...->bo...', w.reshape(w.shape[0], w.shape[1]), x)
+    return y if b is None else y + b.view(1, -1, *([1] * (x.dim() - 2)))
+
+
+def encoder_1x1_forward(x, P, training=True, prefix=''):
+    """Encode3DVAE1x1.forward: three spectral-norm 1x1 blocks + LeakyReLU, then mu / logvar 1x1 convs."""
+    h = x
+    for i in range(3):
+        k = prefix + 'features.conv_block_%d.conv.' % i
+        w = spectral_norm_weight(P[k + 'weight_orig'], P[k + 'weight_u'], P[k + 'weight_v'], training)
+        h = leaky_relu(conv1x1(h, w, P[k + 'bias']))
+    return (conv1x1(h, P[prefix + 'mu.conv.weight'], P[prefix + 'mu.conv.bias']),
+            conv1x1(h, P[prefix + 'logvar.conv.weight'], P[prefix + 'logvar.conv.bias']))
+
+
+def reparameterize_bern(x, eps):
+    """networks_3d.py:38-42 (training branch), eps ~ U(0,1) injected."""
+    return torch.log(x + 1e-20) - torch.log(-torch.log(eps + 1e-20) + 1e-20)
+
+
+def kl_bern_criterion(x):
+    """modules/losses.py:12-14."""
+    kld = x * (torch.log(x + 1e-20) - math.log(0.5)) + (1 - x) * (torch.log(1 - x + 1e-20) - math.log(1 - 0.5))
+    return kld.mean()
+
+
+def generator_vae_nb_forward(P, opt, dims, video, noise_amp, noises, mode='rec', training=True):
+    """GeneratorVAE_nb.forward with the encoder (networks_3d.py:443-485): `noises` yields, in reference order, the normal eps,
+    the uniform eps and then one N(0,1) tensor per level in 'rand' mode (EVERY level: no vae_levels condition here)."""
+    mu, logvar, bern = encoder_nb_forward(video, P, opt, training)
+    z_norm = next(noises) * torch.exp(0.5 * logvar) + mu
+    z_bern = reparameterize_bern(bern, next(noises))
+    vae_out = torch.tanh(_stack7(z_norm * z_bern, P, 'decoder', opt.num_layer))
+    x = vae_out
+    for idx in range(num_body(P)):
+        if opt.vae_levels == idx + 1:
+            x = x.detach()
+            if idx == 0:
+                vae_out = x
+        up = resize_linear_ac(x, level_shape(idx + 1, opt, dims))
+        inp = up + next(noises) * noise_amp[idx + 1] if mode == 'rand' else up
+        x = torch.tanh(_stack7(inp, P, 'body.%d' % idx, opt.num_layer) + up)
+    return x, vae_out, (mu, logvar, bern)
+
+
 def discriminator_forward(x, P, opt, training=True):
     h = _sn_block(x, P, 'head', training)
     for i in range(opt.num_layer):

@@ -64,15 +64,24 @@ class Recorder:
     def __init__(self):
         self.normals = []
         self.rands = []
+        self.draws = []       # every normal_ / uniform_ result in call order (the variant generators mix the two)
 
     def __enter__(self):
         self._normal = torch.Tensor.normal_
+        self._uniform = torch.Tensor.uniform_
         self._rand = torch.rand
         rec = self
+
+        def uniform_(t, *a, **k):
+            r = rec._uniform(t, *a, **k)
+            rec.draws.append(r.detach().clone())
+            return r
+        torch.Tensor.uniform_ = uniform_
 
         def normal_(t, *a, **k):
             r = rec._normal(t, *a, **k)
             rec.normals.append(r.detach().clone())
+            rec.draws.append(r.detach().clone())
             return r
 
         def rand(*a, **k):
@@ -86,6 +95,7 @@ class Recorder:
 
     def __exit__(self, *exc):
         torch.Tensor.normal_ = self._normal
+        torch.Tensor.uniform_ = self._uniform
         torch.rand = self._rand
 
 
@@ -687,6 +697,61 @@ def op_fixtures(images, n3, n2, losses, mutils):
     return out
 
 
+def variant_fixtures(images, n3, n2, losses):
+    """The _nb / 1x1 variants (networks_3d.py:110-160,409-485, networks_2d.py:115-165,272-348, losses.py:12-14): no trainer
+    drives them, so the vectors are module-level: forward values and the gradients of a VAE-style loss."""
+    gen = torch.Generator().manual_seed(21)
+    out = {}
+    for dims, nets in ((3, n3), (2, n2)):
+        opt = make_opt(vae_levels=2, ar=0.75)
+        images.adjust_scales2image(opt.img_size, opt)
+        opt.stop_scale_time = opt.stop_scale
+
+        def shape(i):
+            w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
+            if dims == 3:
+                _, td, _ = images.get_fps_td_by_index(i, opt)
+                return [td, int(w * opt.ar), w]
+            return [int(w * opt.ar), w]
+        torch.manual_seed(31 + dims)
+        G = nets.GeneratorVAE_nb(opt)
+        for _ in range(2):
+            G.init_next_stage()
+        perturb(G, gen)
+        video = torch.rand(2, 3, *shape(0), generator=gen) * 2 - 1
+        real = torch.rand(2, 3, *shape(2), generator=gen) * 2 - 1
+        amps = [1, 0.05, 0.06]
+        sd0 = sd_clone(G)
+        for mode in ('rec', 'rand'):
+            G.load_state_dict(sd0)
+            G.zero_grad()
+            with Recorder() as rec:
+                x, vae_out, (mu, logvar, bern) = G(video, amps, mode=mode)
+            loss = 10.0 * (F.mse_loss(x, real) + F.mse_loss(vae_out, video)) + losses.kl_criterion(mu, logvar) + losses.kl_bern_criterion(bern)
+            loss.backward()
+            out['gen%dd_%s' % (dims, mode)] = {
+                'opt': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, bool, list, str))}, 'dims': dims, 'G_init': sd0,
+                'video': video, 'real': real, 'amps': amps, 'mode': mode, 'draws': rec.draws, 'x': x.detach().clone(),
+                'vae_out': vae_out.detach().clone(), 'mu': mu.detach().clone(), 'logvar': logvar.detach().clone(),
+                'bern': bern.detach().clone(), 'loss': loss.detach().clone(), 'kl_bern': losses.kl_bern_criterion(bern).detach().clone(),
+                'grads': {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in G.named_parameters()},
+                'G_after': sd_clone(G)}
+        # the 1x1 encoder (dead code in the reference, same treatment)
+        torch.manual_seed(41 + dims)
+        E = nets.Encode3DVAE1x1(opt, out_dim=opt.latent_dim)
+        perturb(E, gen)
+        e0 = sd_clone(E)
+        xin = (torch.rand(2, 3, *shape(0), generator=gen) * 2 - 1).requires_grad_(True)
+        mu, logvar = E(xin)
+        gm, gl = torch.randn(mu.shape, generator=gen), torch.randn(logvar.shape, generator=gen)
+        grads = torch.autograd.grad([mu, logvar], [xin] + list(E.parameters()), [gm, gl])
+        out['enc1x1_%dd' % dims] = {'opt': {'nc_im': 3, 'nfc': opt.nfc, 'latent_dim': opt.latent_dim}, 'dims': dims, 'E_init': e0,
+                                    'x': xin.detach().clone(), 'mu': mu.detach().clone(), 'logvar': logvar.detach().clone(), 'gmu': gm, 'glogvar': gl,
+                                    'dx': grads[0].clone(), 'dparams': {n: g.clone() for (n, _), g in zip(E.named_parameters(), grads[1:])},
+                                    'E_after': sd_clone(E)}
+    return out
+
+
 def table_fixtures(images):
     rows = []
     for img_size, min_size, max_size, ar in ((256, 32, 256, 0.5625), (256, 32, 256, 0.75), (256, 48, 256, 0.5625), (64, 32, 256, 0.75),
@@ -710,6 +775,7 @@ def main():
     torch.set_num_threads(1)
     jobs = {
         'ops.pt': lambda: op_fixtures(images, n3, n2, losses, mutils),
+        'variants.pt': lambda: variant_fixtures(images, n3, n2, losses),
         'step3d_vae_s1.pt': lambda: with_kink_margin(lambda sd: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 1, 1, seed=sd), 100, 2e-5),
         'step3d_vae_s0.pt': lambda: with_kink_margin(lambda sd: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 0, 1, seed=sd), 101, 2e-5),
         'step3d_gan_s3.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(vae_levels=2), 3, 3, 1, seed=102),  # 1.5 M kinks: no draw clears a useful margin

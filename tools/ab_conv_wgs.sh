@@ -3,7 +3,7 @@
 # CU (-DHPVG_CONV_WGS4) against the default two, at several pyramid stages.  usage: tools/ab_conv_wgs.sh <outdir>
 out=$1; mkdir -p $out
 c=hp-vae-gan_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DHPVG_CONV_WGS4 -shared -I include -o /tmp/libhpvg_wgs4.so $c/conv_mfma.hip $c/conv_wgrad.hip $c/elementwise.hip $c/frames.hip $c/graph.hip || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DHPVG_CONV_WGS4 -shared -I include -o /tmp/libhpvg_wgs4.so $c/conv_mfma.hip $c/conv_wgrad.hip $c/elementwise.hip $c/frames.hip $c/graph.hip $c/variants.hip || exit 1
 for st in 9 7 5 3; do
   echo "== stage $st: default plan, 2 WG/CU"; python tools/perf_conv.py $st 10 2>/dev/null | grep "conv_fwd 64->64  \|conv_bwd_data"
   echo "== stage $st: NB=2 MB=2, 2 WG/CU"; HPVG_PLAN_NB=2 HPVG_PLAN_MB=2 python tools/perf_conv.py $st 10 2>/dev/null | grep "conv_fwd 64->64  \|conv_bwd_data"

@@ -9,8 +9,7 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 csrc = os.path.join(ROOT, "hp-vae-gan_amd", "csrc")
 if not os.path.exists(out):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DHPVG_TRACE", "-shared"] + os.environ.get("HPVG_TRACE_DEFS", "").split() + [
-                           "-I", os.path.join(ROOT, "include"), "-o", out] + [os.path.join(csrc, f) for f in
-                           ("conv_mfma.hip", "conv_wgrad.hip", "elementwise.hip", "frames.hip")])
+                           "-I", os.path.join(ROOT, "include"), "-o", out] + sorted(__import__("glob").glob(os.path.join(csrc, "*.hip"))))
 os.environ["HPVG_LIB"] = out
 import torch
 import hp_vae_gan_amd
