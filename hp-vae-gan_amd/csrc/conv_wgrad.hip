@@ -17,6 +17,7 @@
 // that the 32 lanes of a half wave (32 different channels, same position) hit 32 different banks.
 #include "hpvg_common.h"
 #include "hpvg.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -424,6 +425,170 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_narrow_kernel(const NarrowA
       for (int e = 0; e < 16; ++e) pp[((m * NT + n) * 16 + e) * 64 + lane] = acc[m][n][e];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Narrow backward-weight, second generation.  The first one stages the 64 wide channels of a tile in LDS by dword LDS-DMA
+// (one instruction per channel and 64 positions) so that a lane can fetch "its channel at position k": 0.36 ms at stage 9,
+// matrix pipe 24 % busy.  Here the wide operand never touches LDS: lane i IS channel i, it reads FOUR consecutive positions
+// of its own channel row with one global_load_dwordx4 (half-wave h takes positions g+4h .. g+4h+3 of an 8-position group) and
+// uses element j as the A operand of MFMA step j - the K index of a step is then the position pair {g+j, g+4+j}, which is as
+// good as any other pairing as long as the B operand (read from the halo'd narrow tile in LDS) uses the same positions.
+// 64 lanes touch 64 different rows, but every 128-byte line they open is consumed by the next three groups from L1/L2, and
+// a load feeds 4 x 2 x NT MFMAs.  Only the narrow operand (<= 4 channels x KT planes, with halo and zero padding) is staged.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+struct Narrow2WArgs {
+  const float* wide;
+  const float* narrow;
+  float* part;
+  int B, CW, CN, T, H, W;
+  int Th, nth, RS, XPL, S, ntiles;
+};
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_narrow2_kernel(const Narrow2WArgs a) {
+  constexpr int TAPS = KT * 9;
+  constexpr int D = 4;   // groups in flight per wave (two 16-byte loads each)
+  extern __shared__ __attribute__((aligned(16))) float nl[];   // narrow tile: CN*KT planes of XPL = (Th+2)*RS floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wb = blockIdx.y;
+  const int RS = a.RS, XPL = a.XPL;
+  const int NROW = a.CN * KT;
+  const long HW = (long)a.H * a.W;
+  const int pt = (KT == 3 ? 1 : 0);
+  const int W = a.W;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  int loff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int j = n * 32 + l31;
+    int o = 0;
+    if (j < a.CN * TAPS) {
+      const int cn = j / TAPS, tap = j - cn * TAPS;
+      const int dt = tap / 9, r = tap - dt * 9, dh = r / 3, dw = r - dh * 3;
+      o = (cn * KT + dt) * XPL + dh * RS + dw;
+    }
+    loff[n] = o;
+  }
+  const int c0 = wb * 64 + l31, c1 = c0 + 32;
+  const bool ok0 = c0 < a.CW, ok1 = c1 < a.CW;
+  const int G8 = (W + 7) / 8;                     // 8-position groups per image row
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+    const int th = tile % a.nth;
+    int r_ = tile / a.nth;
+    const int t = r_ % a.T;
+    const int b = r_ / a.T;
+    const int h0 = th * a.Th;
+    int rows = a.H - h0;
+    if (rows > a.Th) rows = a.Th;
+    __syncthreads();   // every wave is done reading the previous narrow tile
+    // ---- narrow tile with halo and zero padding: plane (cn, dt), tile row hh <-> image row h0+hh-1, column ww <-> ww-1
+    for (int row = 0; row < NROW; ++row) {
+      const int cn = row / KT, dt = row - cn * KT;
+      const int tt = t + dt - pt;
+      const bool tok = tt >= 0 && tt < a.T;
+      const float* src = a.narrow + (((long)b * a.CN + cn) * a.T + (tok ? tt : 0)) * HW;
+      for (int idx = tid; idx < XPL; idx += 256) {
+        const int hh = idx / RS, ww = idx - hh * RS;
+        const int gh = h0 + hh - 1, gw = ww - 1;
+        float v = 0.f;
+        if (tok && gh >= 0 && gh < a.H && gw >= 0 && gw < W) v = src[(long)gh * W + gw];
+        nl[row * XPL + idx] = v;
+      }
+    }
+    __syncthreads();
+    // ---- K loop: the tile's (row, 8-position group) items are dealt round-robin to the four waves (item = wave + 4 k), so a
+    // tile of one or two rows still keeps every wave busy
+    const int total = rows * G8;
+    const int nit = total > wave ? (total - wave + 3) / 4 : 0;
+    const float* w0 = a.wide + (((long)b * a.CW + (ok0 ? c0 : 0)) * a.T + t) * HW + (long)h0 * W;
+    const float* w1 = a.wide + (((long)b * a.CW + (ok1 ? c1 : 0)) * a.T + t) * HW + (long)h0 * W;
+    f32x4u A0[D], A1[D];
+    auto issue = [&](int it, f32x4u& x0, f32x4u& x1) {
+      const int item = wave + 4 * it;
+      const int rr = item / G8, g = 8 * (item - rr * G8);
+      int start = g + 4 * half;
+      if (start > W - 4) start = W - 4;
+      x0 = *reinterpret_cast<const f32x4u*>(w0 + (long)rr * W + start);
+      x1 = *reinterpret_cast<const f32x4u*>(w1 + (long)rr * W + start);
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (u < nit) issue(u, A0[u], A1[u]);
+    for (int it0 = 0; it0 < nit; it0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int it = it0 + u;
+        if (it < nit) {
+          const int item = wave + 4 * it;
+          const int rr = item / G8, g = 8 * (item - rr * G8);
+          const int gs = g + 4 * half;
+          int start = gs;
+          if (start > W - 4) start = W - 4;
+          const f32x4u x0 = A0[u], x1 = A1[u];
+          if (it + D < nit) issue(it + D, A0[u], A1[u]);
+          const float* bl = nl + rr * RS + start;               // tap (dh, dw) of position (tile row rr, column c) sits at (rr + dh) * RS + c + dw
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pos = start + j;
+            const bool v = pos >= gs && pos < W;                // (a clamped tail group re-reads columns an earlier group owns)
+            const float a0 = (v && ok0) ? x0[j] : 0.f;
+            const float a1 = (v && ok1) ? x1[j] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const float bv = bl[loff[n] + j];
+              acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][n], 0, 0, 0);
+              acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // the four waves' partial sums are added up through LDS in wave order (fixed order: reproducible) and the workgroup
+  // writes ONE fragment set: part[wg][wb][m][n][e][lane] (the reduce kernel sees gridDim.x partials per 64-channel block)
+  __syncthreads();                       // the narrow tile is dead: its LDS becomes the exchange buffer
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) nl[((m * NT + n) * 16 + e) * 64 + lane] = acc[m][n][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[m][n][e] += nl[((m * NT + n) * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float* pp = a.part + (((long)blockIdx.x * gridDim.y + wb) * 2 * NT) * 1024;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pp[((m * NT + n) * 16 + e) * 64 + lane] = acc[m][n][e];
+  }
+}
+
 // dW from the narrow kernel's fragments; mode 0: dW[o=cw][c=cn][tap]; mode 1: dW[o=cn][c=cw][ntaps-1-tap]
 // one wave per output element: lanes stride over the partial slabs, fixed-order shuffle reduction (reproducible)
 __global__ __launch_bounds__(256) void conv_wgrad_narrow_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -608,12 +773,41 @@ inline int narrow_mode(int Cin, int Cout) {
   if (Cout <= 4 && Cin > 4) return 1;
   return -1;
 }
+// tile plan of conv_wgrad_narrow2_kernel: Th image rows per tile such that the halo'd narrow tile (CN*KT planes) fits 60 KB
+struct N2Plan { int Th, nth, RS, XPL, S; long ntiles; size_t lds; bool ok; };
+inline N2Plan plan_narrow2w(int B, int CW, int CN, int T, int H, int W, int KT) {
+  N2Plan q{};
+  q.ok = false;
+  if (W < 4) return q;
+  const int RS = W + 2, NROW = CN * KT;
+  int Th = (int)((60 * 1024 / sizeof(float)) / ((size_t)NROW * RS)) - 2;
+  if (Th < 1) return q;
+  if (Th > H) Th = H;
+  // enough tiles to fill the chip twice over (small pyramid stages): ~1024 tiles per 64-channel block
+  const long want_rows = ((long)H * B * T + 1023) / 1024;
+  if (Th > want_rows) Th = (int)(want_rows < 1 ? 1 : want_rows);
+  const int nth = hpvg_cdiv(H, Th);
+  Th = hpvg_cdiv(H, nth);                      // balanced
+  const int nwb = hpvg_cdiv(CW, 64);
+  q.Th = Th; q.nth = nth; q.RS = RS; q.XPL = (Th + 2) * RS;
+  q.ntiles = (long)B * T * nth;
+  long S = 2L * HPVG_NUM_CU / nwb;             // two workgroups per CU
+  if (S < 1) S = 1;
+  if (q.ntiles < S) S = q.ntiles;
+  q.S = (int)S;
+  q.lds = (size_t)NROW * q.XPL * sizeof(float);
+  const size_t xch = (size_t)2 * hpvg_cdiv(CN * KT * 9, 32) * 1024 * sizeof(float);   // the waves' end-of-kernel exchange buffer
+  if (q.lds < xch) q.lds = xch;
+  q.ok = true;
+  return q;
+}
+static const bool g_narrow2w_off = [] { const char* e = getenv("HPVG_WGRAD_NARROW2"); return e && atoi(e) == 0; }();
+
 inline size_t narrow_ws_bytes(const WPlan& p, int CW, int CN, int KT, long ntiles) {
   const int nwb = hpvg_cdiv(CW, 64);
   const int NT = hpvg_cdiv(CN * KT * 9, 32);
-  long S = HPVG_NUM_CU / nwb;
+  long S = 2L * HPVG_NUM_CU / nwb;             // the larger of the two generations' grids
   if (S < 1) S = 1;
-  if (ntiles < S) S = ntiles;
   return 256 + (size_t)S * 4 * nwb * 2 * NT * 1024 * sizeof(float);
 }
 
@@ -647,10 +841,42 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
     if (ws_bytes < narrow_ws_bytes(p, CW, CN, KT, ntiles)) return HPVG_ERR_WORKSPACE;
     const int nwb = hpvg_cdiv(CW, 64);
     const int NT = hpvg_cdiv(CN * KT * 9, 32);
+    hipStream_t s = (hipStream_t)stream;
+    const N2Plan q = plan_narrow2w(B, CW, CN, T, H, W, KT);
+    if (q.ok && !g_narrow2w_off) {
+      // ---- second generation: the wide operand straight from global memory, 16 bytes per lane (conv_wgrad_narrow2_kernel)
+      Narrow2WArgs n2;
+      n2.wide = nm == 0 ? dy : x; n2.narrow = nm == 0 ? x : dy; n2.part = (float*)((char*)ws + 256);
+      n2.B = B; n2.CW = CW; n2.CN = CN; n2.T = T; n2.H = H; n2.W = W;
+      n2.Th = q.Th; n2.nth = q.nth; n2.RS = q.RS; n2.XPL = q.XPL; n2.S = q.S; n2.ntiles = (int)q.ntiles;
+      const dim3 grid2((unsigned)q.S, nwb);
+#define HPVG_NW2_LAUNCH(K, N)                                                                                         \
+  {                                                                                                                   \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_narrow2_kernel<K, N>),                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                  \
+        (void)hipGetLastError();                                                                                      \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((conv_wgrad_narrow2_kernel<K, N>), grid2, dim3(256), q.lds, s, n2);                            \
+  }
+      if (KT == 3) {
+        if (NT == 1) HPVG_NW2_LAUNCH(3, 1) else if (NT == 2) HPVG_NW2_LAUNCH(3, 2) else if (NT == 3) HPVG_NW2_LAUNCH(3, 3) else HPVG_NW2_LAUNCH(3, 4)
+      } else {
+        if (NT == 1) HPVG_NW2_LAUNCH(1, 1) else HPVG_NW2_LAUNCH(1, 2)
+      }
+#undef HPVG_NW2_LAUNCH
+      int st2 = hpvg_launch_status();
+      if (st2 != HPVG_OK) return st2;
+      const int total2 = CW * CN * KT * 9;
+      hipLaunchKernelGGL(conv_wgrad_narrow_reduce_kernel, dim3(hpvg_cdiv(total2, 4)), dim3(256), 0, s, (const float*)n2.part, dw,
+                         q.S, nwb, NT, CW, CN, KT * 9, nm, accumulate);
+      return hpvg_launch_status();
+    }
     long S = HPVG_NUM_CU / nwb;
     if (S < 1) S = 1;
     if (ntiles < S) S = ntiles;
-    hipStream_t s = (hipStream_t)stream;
     NarrowArgs na;
     na.wide = nm == 0 ? dy : x; na.narrow = nm == 0 ? x : dy; na.part = (float*)((char*)ws + 256);
     na.B = B; na.CW = CW; na.CN = CN; na.T = T; na.H = H; na.W = W;
