@@ -954,6 +954,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
   // development knobs: restrict the search to one NB / MB
   static const int only_nb = [] { const char* e = getenv("HPVG_PLAN_NB"); return e ? atoi(e) : 0; }();
   static const int only_mb = [] { const char* e = getenv("HPVG_PLAN_MB"); return e ? atoi(e) : 0; }();
+  static const int only_ntw = [] { const char* e = getenv("HPVG_PLAN_NTW"); return e ? atoi(e) : 0; }();
   if (narrow) {
     // 2-D tiles (Th x Tw) for conv_narrow_kernel: a GEMM over the tile + halo positions, one workgroup per tile: blocks
     // of 32 positions over 4 waves, K steps of 64 cycles each, ~3 us of epilogue; the P image (9*Cout rows) must leave
@@ -989,6 +990,7 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
     for (int ntw = 1; ntw <= W; ++ntw) {
       const int Tw = hpvg_cdiv(W, ntw);
       if (ntw > 1 && hpvg_cdiv(W, ntw - 1) == Tw) continue;  // same band width as the previous ntw: more bands, no gain
+      if (only_ntw && ntw != only_ntw) continue;
       const int RS = Tw + 2;
       const long flat = (long)(H - 1) * RS + Tw;  // flattened positions that hold outputs
       // candidate tiles of this band.  3x3x3: balanced ranges of at most NB*128 positions.  3x3 (a third of the MFMA work
