@@ -276,6 +276,31 @@ def _single_process(fname):
     return fx, out, PG, PD, amps
 
 
+def _check_updates(tag, fx, got, PG, PD):
+    """Optimizer steps are judged by their UPDATE against the single-process step's (helpers.compare_update): a parameter the
+    single-process step leaves alone must stay bit-identical, a trained one must move by the same amount - its first Adam
+    step is +-lr wherever the gradient is not zero, so max |update| of the single-process run IS the parameter's learning
+    rate.  Spectral-norm u / v (buffers) are compared directly."""
+    from helpers import _bn_fed_bias, assert_close, compare_update, oracle_state
+    from oracle import hpvg_oracle as O
+    for which, ref, init in (("G", PG, fx["G_init"]), ("D", PD, fx["D_init"])):
+        if ref is None:
+            continue
+        before = oracle_state(init)
+        names = set(k for k in ref if O.is_param(k))
+        for k, v in ref.items():
+            if O.is_param(k):
+                # (a bias feeding a BatchNorm has an exactly-zero true gradient: its step size is the sibling weight's)
+                kk = k[:-len("bias")] + "weight" if _bn_fed_bias(k, names) else k
+                step = float((ref[kk].detach().double() - before[kk].double()).abs().max())
+                compare_update("%s.%s.%s" % (tag, which, k), before[k].detach(), v.detach(), got[which][k], step if step > 0 else None, 0.0,
+                               _bn_fed_bias(k, names))
+            elif which == "D" and k.endswith(("weight_u", "weight_v")):
+                # (the G step's critic forward runs its power iteration on the UPDATED weights, where the few sign-flipped
+                # Adam steps of near-zero gradients differ between any two evaluation orders: 1e-3, north_star's tolerance)
+                assert_close(got[which][k], v, 1e-3, "%s.%s.%s" % (tag, which, k), atol=1e-6)
+
+
 def _check_generator_buffers(fname, got, PG, nranks):
     """After sync_buffers every rank holds the SINGLE-GPU generator buffers: BatchNorm running statistics follow the
     reference's rec-then-rand update sequence, the encoder's spectral-norm u / v are the rec pass's (unit vectors),
@@ -303,19 +328,12 @@ def test_distributed_step_matches_single_process(fname, world):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), fname, d), nprocs=world, join=True)
         got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(2)]
-    lr = fx["opt"]["lr_g"]
     for r in range(2):
         assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
         for k in ("errD_real", "errD_fake", "gradient_penalty", "errG"):
             if k in want:
                 assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
-        for k, v in PG.items():
-            if O.is_param(k):
-                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
-        if PD is not None:
-            for k, v in PD.items():
-                if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
-                    assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+        _check_updates("%s.rank%d" % (fname, r), fx, got[r], PG, PD)
     _check_generator_buffers(fname, got, PG, 2)
     # the two working ranks hold bit-identical replicas after the step
     for k in got[0]["G"]:
@@ -337,17 +355,11 @@ def test_quad_step_matches_single_process(fname, world):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), fname, d, True), nprocs=world, join=True)
         got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(4)]
-    lr = fx["opt"]["lr_g"]
     for r in range(4):
         assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
         for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
             assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
-        for k, v in PG.items():
-            if O.is_param(k):
-                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
-        for k, v in PD.items():
-            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
-                assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+        _check_updates("%s.rank%d" % (fname, r), fx, got[r], PG, PD)
     _check_generator_buffers(fname, got, PG, 4)
     for r in range(1, 4):
         for k in got[0]["G"]:
@@ -370,17 +382,11 @@ def test_oct_step_matches_single_process(fname, slab_levels):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(8, _free_port(), fname, d, True, 2, slab_levels), nprocs=8, join=True)
         got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(8)]
-    lr = fx["opt"]["lr_g"]
     for r in range(8):
         assert got[r]["amps"] == pytest.approx(amps, rel=1e-5)
         for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
             assert_close(got[r]["out"][k], want[k], 2e-4, "%s.rank%d.%s" % (fname, r, k))
-        for k, v in PG.items():
-            if O.is_param(k):
-                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
-        for k, v in PD.items():
-            if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
-                assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+        _check_updates("%s.rank%d" % (fname, r), fx, got[r], PG, PD)
     _check_generator_buffers(fname, got, PG, 8)
     for r in range(1, 8):
         for k in got[0]["G"]:

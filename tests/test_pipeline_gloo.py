@@ -16,7 +16,7 @@ for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from test_multigpu_gloo import OracleNet, TorchBackend, _free_port, _groups, _single_process  # noqa: E402
+from test_multigpu_gloo import OracleNet, TorchBackend, _check_updates, _free_port, _groups, _single_process  # noqa: E402
 
 
 class TorchPipeBackend(TorchBackend):
@@ -133,7 +133,6 @@ def test_level_pipeline_matches_single_process(fname, world):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), fname, d), nprocs=world, join=True)
         got = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=True) for r in range(world)]
-    lr = fx["opt"]["lr_g"]
     assert len(got[0]["parts"]) == min(world, fx["scale_idx"] + 1)
     if world == fx["scale_idx"] + 1:
         assert [tuple(p) for p in got[0]["parts"]] == [(k, k) for k in range(world)], "one pyramid level per rank"
@@ -143,13 +142,7 @@ def test_level_pipeline_matches_single_process(fname, world):
             if k in want and k in got[r]["out"]:
                 assert_close(torch.tensor(got[r]["out"][k]), want[k].float().reshape(()), 2e-4, "%s.rank%d.%s" % (fname, r, k))
         # after broadcast_levels every rank holds the owners' parameters
-        for k, v in PG.items():
-            if O.is_param(k):
-                assert_close(got[r]["G"][k], v, 1e-4, "%s.rank%d.G.%s" % (fname, r, k), atol=2 * lr)
-        if PD is not None:
-            for k, v in PD.items():
-                if O.is_param(k) or k.endswith(("weight_u", "weight_v")):
-                    assert_close(got[r]["D"][k], v, 1e-4, "%s.rank%d.D.%s" % (fname, r, k), atol=2 * lr)
+        _check_updates("%s.rank%d" % (fname, r), fx, got[r], PG, PD)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
