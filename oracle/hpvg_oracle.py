@@ -101,15 +101,52 @@ def leaky_relu(x):
     return torch.where(x > 0, x, LRELU_SLOPE * x)
 
 
+def _bn_backward(x, gamma, dy):
+    """The batch-norm backward in its fused form (the formula torch's native kernel evaluates, sums accumulated in double
+    as ATen's CPU kernel does):  dx = gamma * invstd / N * (N dy - sum dy - xhat sum(dy xhat)),  dgamma = sum(dy xhat),
+    dbeta = sum dy.  Written with differentiable ops on the INPUTS, so a gradient penalty can differentiate it again
+    (WDiscriminatorBaselines, modules/networks_3d.py:216-247 under modules/utils.py:4-19)."""
+    dimsr = [0] + list(range(2, x.dim()))
+    shape = (1, -1) + (1,) * (x.dim() - 2)
+    n = x.numel() // x.shape[1]
+    mean = x.mean(dim=dimsr)
+    var = ((x - mean.view(shape)) ** 2).mean(dim=dimsr)
+    invstd = 1.0 / torch.sqrt(var + BN_EPS)
+    xhat = (x - mean.view(shape)) * invstd.view(shape)
+    sdy = dy.sum(dim=dimsr, dtype=torch.float64)
+    sdyx = (dy * xhat).sum(dim=dimsr, dtype=torch.float64)
+    dx = (gamma * invstd / n).view(shape) * (n * dy - sdy.float().view(shape) - xhat * sdyx.float().view(shape))
+    return dx, sdyx.float(), sdy.float()
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """Forward = the definition; backward = the fused formula above.  (Letting autograd differentiate the forward
+    expression term by term gives the same derivative in exact arithmetic but amplifies fp32 rounding by invstd on
+    nearly constant channels - 4e-3 relative between two thread counts on tests/golden/wide2d_vae_s1.pt, where the
+    reference's own evaluations agree to 1e-8.)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        dimsr = [0] + list(range(2, x.dim()))
+        shape = (1, -1) + (1,) * (x.dim() - 2)
+        mean = x.mean(dim=dimsr)
+        var = ((x - mean.view(shape)) ** 2).mean(dim=dimsr)
+        y = (x - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS) * gamma.view(shape) + beta.view(shape)
+        ctx.save_for_backward(x, gamma)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, gamma = ctx.saved_tensors
+        return _bn_backward(x, gamma, dy)
+
+
 def batch_norm_train(x, gamma, beta, running_mean=None, running_var=None):
     """Per-channel batch statistics over (B, spatial); biased variance for normalisation, unbiased for the
     running_var update; running <- 0.9*running + 0.1*stat (in place)."""
-    dimsr = [0] + list(range(2, x.dim()))
     n = x.numel() // x.shape[1]
-    mean = x.mean(dim=dimsr)
-    var = ((x - mean.view(1, -1, *([1] * (x.dim() - 2)))) ** 2).mean(dim=dimsr)
-    shape = (1, -1) + (1,) * (x.dim() - 2)
-    y = (x - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS) * gamma.view(shape) + beta.view(shape)
+    y, mean, var = _BatchNormTrain.apply(x, gamma, beta)
     if running_mean is not None:
         with torch.no_grad():
             running_mean.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())

@@ -123,6 +123,33 @@ class KinkMargin:
             h.remove()
 
 
+class KinkFlip:
+    """Re-run helper for fixtures with millions of activations, where no draw can stay clear of the LeakyReLU kinks: every
+    LeakyReLU input with |z| < tau has its sign flipped (forward_pre_hook; the value moves by < 2 tau, the gradient mask
+    jumps).  The difference to the plain run is what the kink elements can do to each recorded quantity - part of the
+    fixture's spread, so that a correct implementation whose rounding lands on the other side of a kink still passes."""
+
+    def __init__(self, tau, *modules):
+        self.tau, self.flipped, self.handles = tau, 0, []
+        for m in modules:
+            if m is None:
+                continue
+            for sub in m.modules():
+                if isinstance(sub, torch.nn.LeakyReLU):
+                    self.handles.append(sub.register_forward_pre_hook(self._hook))
+
+    def _hook(self, mod, inp):
+        z = inp[0]
+        near = z.detach().abs() < self.tau
+        self.flipped += int(near.sum())
+        return (torch.where(near, z - 2 * z.detach(), z),)   # value -z, derivative of the identity
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+KINK_FLIP = [0.0]        # wide_fixture(): tau of the kink-flipped re-run (0 = off)
 SEED_OVERRIDE = [None]   # main(): re-run a job on exactly the seed its first run settled on
 # main(): relative perturbation applied to the input clip of a re-run (2^-20: the size of the difference between two fp32
 # implementations after a few dozen layers).  The spread between the plain and the perturbed run is how much the reference
@@ -374,6 +401,7 @@ def run_wide_step(images, nets, losses, mutils, opt, dims, scale_idx, threads):
         optimizerD = optim.Adam(D.parameters(), lr=opt.lr_d, betas=(opt.beta1, 0.999))
     optimizerG = optim.Adam(g_param_list(netG, opt, scale_idx), lr=opt.lr_g, betas=(opt.beta1, 0.999))
     G0, D0 = sd_clone(netG), (sd_clone(D) if gan else None)
+    flipper = KinkFlip(KINK_FLIP[0], netG, D) if KINK_FLIP[0] else None
 
     def shape(i):
         w = images.get_scales_by_index(i, opt.scale_factor, opt.stop_scale, opt.img_size)
@@ -431,6 +459,9 @@ def run_wide_step(images, nets, losses, mutils, opt, dims, scale_idx, threads):
     out.update(total_loss=float(total_loss), total_norm=float(total_norm), noise_amps=list(noise_amps), noise_shapes=rec.shapes,
                alpha=DetNoise.ALPHA, generated=detfill.summarize(generated, 4096), generated_vae=detfill.summarize(generated_vae, 4096),
                mu=detfill.summarize(mu, 4096), logvar=detfill.summarize(logvar, 4096))
+    if flipper is not None:
+        flipper.close()
+        out['kink_flipped'] = flipper.flipped
     G1 = sd_clone(netG)
     out['G_delta'] = {k: detfill.summarize(G1[k].float() - G0[k].float(), 256) for k, _ in netG.named_parameters()}
     out['G_buffers'] = {k: v.clone() for k, v in G1.items() if k.endswith(('running_mean', 'running_var', 'weight_u', 'weight_v', 'num_batches_tracked'))}
@@ -458,9 +489,9 @@ def _spread(a, b):
     return None
 
 
-def wide_fixture(images, nets, losses, mutils, dims, scale_idx):
+def wide_fixture(images, nets, losses, mutils, dims, scale_idx, ar=144.0 / 256.0):
     def opt():
-        return make_opt(nfc=64, latent_dim=128, vae_levels=3, min_size=32, max_size=256, img_size=256, ar=144.0 / 256.0)
+        return make_opt(nfc=64, latent_dim=128, vae_levels=3, min_size=32, max_size=256, img_size=256, ar=ar)
     one = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
     with torch.backends.mkldnn.flags(enabled=False):   # 8 threads AND ATen's native conv kernels instead of oneDNN
         many = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=8)
@@ -474,21 +505,27 @@ def wide_fixture(images, nets, losses, mutils, dims, scale_idx):
         noisy = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
     finally:
         GRAD_NOISE[0] = 0.0
+    KINK_FLIP[0] = 2e-6      # activations are O(1); two fp32 evaluations differ by ~1e-6 after a few dozen layers
+    try:
+        flipped = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
+    finally:
+        KINK_FLIP[0] = 0.0
+    nflip = flipped.pop('kink_flipped')
     torch.set_num_threads(1)
     o = opt()
     images.adjust_scales2image(o.img_size, o)
     lr = o.lr_g
-    spread = merge_spread(merge_spread(_spread(one, many), _spread(one, pert)), _spread(one, noisy))
+    spread = merge_spread(merge_spread(merge_spread(_spread(one, many), _spread(one, pert)), _spread(one, noisy)), _spread(one, flipped))
     for name in ('G_delta', 'D_delta'):   # fraction of sampled weights whose update differs by more than lr/10 between the runs
         if name in one:
             for k in one[name]:
                 fr = 0.0
-                for other in (many, pert, noisy):
+                for other in (many, pert, noisy, flipped):
                     d = (one[name][k]['sample'].double() - other[name][k]['sample'].double()).abs()
                     fr = max(fr, float((d > lr / 10).double().mean()))
                 spread[name][k]['frac_lr10'] = fr
     return {'opt': {k: v for k, v in vars(o).items() if isinstance(v, (int, float, bool, list, str))}, 'dims': dims,
-            'scale_idx': scale_idx, 'expected': one, 'spread': spread}
+            'scale_idx': scale_idx, 'expected': one, 'spread': spread, 'kink_flipped': nflip}
 
 
 def run_baseline_steps(images, n3, mutils, opt, scale_idx, n_iters, seed, generator='GeneratorSG', discriminator='WDiscriminator3D'):
@@ -801,6 +838,9 @@ def main():
         # whole steps at the BASELINE widths (nfc 64, latent 128, 256-wide pyramid): closed-form inputs, output summaries
         'wide3d_vae_s0.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 0),
         'wide3d_gan_s3.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 3),
+        # the 2-D path at the same widths (BASELINE configs[1]: train_image.py air_balloons.jpg, 248x186 -> ar 0.75)
+        'wide2d_vae_s1.pt': lambda: wide_fixture(images, n2, losses, mutils, 2, 1, ar=186.0 / 248.0),
+        'wide2d_gan_s4.pt': lambda: wide_fixture(images, n2, losses, mutils, 2, 4, ar=186.0 / 248.0),
         # 8-level pyramids (BASELINE configs[3] / configs[4]: one level per GPU on 8 GPUs), tiny widths: the world-8 gloo tests
         'step3d_gan_s7.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(**small8), 3, 7, 1, seed=111),
         'baseline3d_sg_s7.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=1, **small8),

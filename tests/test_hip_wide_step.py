@@ -10,7 +10,7 @@ from helpers import NoiseFeed, flat_to_named, hip_opt, load_golden, wide_compare
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fname", ["wide3d_vae_s0.pt", "wide3d_gan_s3.pt"])
+@pytest.mark.parametrize("fname", ["wide3d_vae_s0.pt", "wide3d_gan_s3.pt", "wide2d_vae_s1.pt", "wide2d_gan_s4.pt"])
 def test_wide_train_step_matches_reference(fname):
     import hp_vae_gan_amd as hp  # noqa: F401
     from hp_vae_gan_amd import train as hp_train
