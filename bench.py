@@ -442,7 +442,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[CONFIG] + "; step = 1 train iteration at each pyramid stage %s" % args.stages,
                        "stages": stages,
-                       "hipgraph_stages": ([s for s in graph_stages if s in stages and CONFIG != "baseline"] if world == 1 else
+                       "hipgraph_stages": ([s for s in graph_stages if s in stages] if world == 1 else
                                            [s for s in stages if s < 3 and os.environ.get("HPVG_VAE_ON_RANK0", "1") != "0"
                                             and parallelism_mode() != "levels" and CONFIG != "baseline"]),
                        "parallelism": _parallelism(world)},

@@ -58,6 +58,50 @@ def generator_param_groups(opt, netG):
     return groups
 
 
+def _capture_iteration(trainer, run, nets):
+    """Capture `run()` - one eager iteration of `trainer` on its static input buffers - into a hipGraph.  Sets
+    trainer._graph / _g_out / _graph_bn / graph_nodes; leaves trainer.iteration where it was (capture records the launches,
+    it does not execute the iteration).  Shared by StageTrainer and BaselineStageTrainer."""
+    ops.pin_workspaces()  # the graph bakes in scratch addresses: they must outlive later (larger) stages' buffers
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()  # warm-up on the capture stream's side (allocator, workspaces)
+    torch.cuda.current_stream().wait_stream(side)
+    it = trainer.iteration
+    graph = torch.cuda.CUDAGraph(keep_graph=True)   # keep the hipGraph_t: its nodes are inspected below
+    # host-side state that python advances while it records the iteration: BatchNorm forward counts (replays must add
+    # the same amounts, the capture itself must not count)
+    bns = [m for net in nets if net is not None for m in net.modules() if hasattr(m, 'pending_batches')]
+    before = [m.pending_batches for m in bns]
+    ops.weights_changed()  # packed weights made outside the capture must not be baked into it, nor its buffers reused after
+    with torch.cuda.graph(graph):
+        trainer._g_out = run()
+    ops.weights_changed()
+    trainer.graph_nodes = graph_node_census(graph)
+    bad = {k: v for k, v in trainer.graph_nodes.items() if k not in ("kernel", "empty", "event_record", "wait_event") and v}
+    if bad:
+        # memcpy / memset nodes are not reliably ordered against kernel nodes on this runtime (DESIGN.md section 4: replays
+        # trained NaNs); whatever put them there (a torch fill / slice-backward / pad lowering) must become a kernel
+        trainer._graph = None
+        raise RuntimeError("the captured iteration holds non-kernel graph nodes %s (of %s): refusing to replay it" % (bad, trainer.graph_nodes))
+    graph.instantiate()
+    trainer._graph = graph
+    trainer._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
+    for m, b in zip(bns, before):
+        m.pending_batches = b
+    trainer.iteration = it
+
+
+def _replay_iteration(trainer):
+    trainer._graph.replay()
+    ops.weights_changed()  # the replayed Adam kernels moved the weights without passing through python
+    for m, d in trainer._graph_bn:
+        m.pending_batches += d
+    trainer.iteration += 1
+    return trainer._g_out
+
+
 class StageTrainer:
     """State of one pyramid stage: discriminator, arenas and optimisers (train_video.py:38-96), plus `step()` =
     one iteration of the hot loop (train_video.py:111-202)."""
@@ -113,34 +157,7 @@ class StageTrainer:
         self._g_real = real.clone()
         self._g_rz = self._g_real if real_zero is real else real_zero.clone()
         self._graph_alpha = True
-        ops.pin_workspaces()  # the graph bakes in scratch addresses: they must outlive later (larger) stages' buffers
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._step_eager(self._g_real, self._g_rz)  # warm-up on the capture stream's side (allocator, workspaces)
-        torch.cuda.current_stream().wait_stream(side)
-        it = self.iteration
-        self._graph = torch.cuda.CUDAGraph(keep_graph=True)   # keep the hipGraph_t: its nodes are inspected below
-        # host-side state that python advances while it records the iteration: BatchNorm forward counts (replays must add
-        # the same amounts, the capture itself must not count)
-        bns = [m for net in (self.netG, self.netD) if net is not None for m in net.modules() if hasattr(m, 'pending_batches')]
-        before = [m.pending_batches for m in bns]
-        ops.weights_changed()  # packed weights made outside the capture must not be baked into it, nor its buffers reused after
-        with torch.cuda.graph(self._graph):
-            self._g_out = self._step_eager(self._g_real, self._g_rz)
-        ops.weights_changed()
-        self.graph_nodes = graph_node_census(self._graph)
-        bad = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "empty", "event_record", "wait_event") and v}
-        if bad:
-            # memcpy / memset nodes are not reliably ordered against kernel nodes on this runtime (replays
-            # trained NaNs); whatever put them there (a torch fill / slice-backward / pad lowering) must become a kernel
-            self._graph = None
-            raise RuntimeError("the captured iteration holds non-kernel graph nodes %s (of %s): refusing to replay it" % (bad, self.graph_nodes))
-        self._graph.instantiate()
-        self._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
-        for m, b in zip(bns, before):
-            m.pending_batches = b
-        self.iteration = it  # capture records the launches, it does not execute the iteration
+        _capture_iteration(self, lambda: self._step_eager(self._g_real, self._g_rz), (self.netG, self.netD))
         return self
 
     def step(self, real, real_zero, noise_init=None, alpha=None):
@@ -151,13 +168,8 @@ class StageTrainer:
                 self._g_real.copy_(real)
             if real_zero.data_ptr() != self._g_rz.data_ptr() and self._g_rz is not self._g_real:
                 self._g_rz.copy_(real_zero)
-            self._graph.replay()
-            ops.weights_changed()  # the replayed Adam kernels moved the weights without passing through python
-            for m, d in self._graph_bn:
-                m.pending_batches += d
-            self.iteration += 1
-            self.last = self._g_out
-            return self._g_out
+            self.last = _replay_iteration(self)
+            return self.last
         return self._step_eager(real, real_zero, noise_init, alpha)
 
     def _step_eager(self, real, real_zero, noise_init=None, alpha=None):
@@ -285,10 +297,29 @@ class BaselineStageTrainer:
         self.iteration = 0
         self.after_d_step = None   # test hook: callable(trainer, j) after the j-th discriminator update (see StageTrainer)
 
+    def enable_graph(self, real, real_zero=None):
+        """Capture one iteration into a hipGraph and replay it from then on (see StageTrainer.enable_graph: call after >= 1
+        eager iteration; the gradient penalties' alphas then come from the device generator)."""
+        if self.iteration < 1:
+            raise RuntimeError("run one eager iteration first (noise-amplitude calibration is not capturable)")
+        self._g_real = real.clone()
+        self._graph_alpha = True
+        _capture_iteration(self, lambda: self._step_eager(self._g_real), (self.netG, self.netD))
+        return self
+
     def step(self, real, noise_init=None, alphas=None):
+        if getattr(self, '_graph', None) is not None and noise_init is None and alphas is None:
+            if real.data_ptr() != self._g_real.data_ptr():
+                self._g_real.copy_(real)
+            return _replay_iteration(self)
+        return self._step_eager(real, noise_init, alphas)
+
+    def _step_eager(self, real, noise_init=None, alphas=None):
         opt, netG, netD = self.opt, self.netG, self.netD
         if real.is_cuda:
             ops.rng_next_iteration(real.device)
+        if alphas is None and getattr(self, '_graph_alpha', False):
+            alphas = [torch.rand(1, device=real.device) for _ in range(opt.Dsteps)]
         if noise_init is None:
             noise_init = utils.generate_noise(ref=opt.Z_init)
         if self.iteration == 0:

@@ -250,6 +250,68 @@ def test_graph_replay_equals_eager(fname):
     assert b_tr.iteration == a_tr.iteration == 8
 
 
+@pytest.mark.parametrize("fname,critic", [("baseline3d_s2.pt", "WDiscriminator3D"), ("baseline3d_dbl_s1.pt", "WDiscriminatorBaselines")])
+def test_baseline_graph_replay_tracks_eager(fname, critic):
+    """hipGraph capture of the baselines' iteration (BaselineStageTrainer.enable_graph; Dsteps = 2 in baseline3d_s2, the
+    BatchNorm critic and its double backward in baseline3d_dbl_s1): the captured graph holds kernel nodes only (enable_graph
+    refuses anything else), replays stay finite with a device synchronise in between, and after 8 iterations the
+    parameters sit within the Adam step scale of an eager run fed the same noise (the alphas differ: device generator
+    offsets under capture), BatchNorm counters included."""
+    from helpers import hip_opt
+    from hp_vae_gan_amd import train as hp_train
+    from hp_vae_gan_amd.modules import networks_3d
+    fx = load_golden(fname)
+    dev = "cuda"
+    s = fx["scale_idx"]
+    rec = fx["iters"][0]
+
+    def build():
+        opt = hip_opt(fx["opt"], 3, s, dev)
+        netG = networks_3d.GeneratorSG(opt)
+        for _ in range(s):
+            netG.init_next_stage()
+        netG.load_state_dict(fx["G_init"])
+        netG.to(dev)
+        netD = getattr(networks_3d, critic)(opt)
+        netD.load_state_dict(fx["D_init"])
+        netD.to(dev)
+        opt.Noise_Amps = list(fx["noise_amps_init"])
+        opt.Z_init = fx["Z_init"].to(dev)
+        tr = hp_train.BaselineStageTrainer(opt, netG, netD)
+        noises = {tuple(t.shape): t.to(dev) for t in rec["noises"]}
+        netG.noise_source = lambda ref: noises[tuple(ref.shape)]     # the same draw for a given shape, every time
+        return tr, netG, netD
+
+    real = fx["real"].to(dev)
+    a_tr, a_G, a_D = build()
+    torch.manual_seed(7)
+    a_tr.step(real)
+    a_tr._graph_alpha = True
+    for _ in range(7):
+        a_tr.step(real)
+    b_tr, b_G, b_D = build()
+    torch.manual_seed(7)
+    b_tr.step(real)
+    b_tr.enable_graph(real)              # one warm-up iteration (eager, side stream) + capture
+    assert b_tr.graph_nodes.get("kernel", 0) > 50 and not b_tr.graph_nodes.get("memset", 0) and not b_tr.graph_nodes.get("memcpy", 0)
+    for _ in range(6):
+        out = b_tr.step(real)            # replays
+        torch.cuda.synchronize()
+        for k in ("errD_real", "errD_fake", "gradient_penalty", "errG", "rec_loss"):
+            assert torch.isfinite(out[k]).all(), k
+    assert b_tr.iteration == a_tr.iteration == 8
+    lr = fx["opt"]["lr_g"] * 8
+    for net_a, net_b, tag in ((a_G, b_G, "G"), (a_D, b_D, "D")):
+        for (k, va), (_, vb) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+            assert torch.isfinite(vb.float()).all(), k
+            if k.endswith("num_batches_tracked"):
+                assert int(va) == int(vb), "%s.%s: %d vs %d forward passes counted" % (tag, k, int(va), int(vb))
+            elif not k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+                # (bound of two Adam trajectories that see different alphas: 2 lr per optimizer step, Dsteps of them per iteration)
+                steps = fx["opt"]["Dsteps"] if tag == "D" else 1
+                assert_close(vb.float(), va.float(), 2e-2, "baseline.graph.%s.%s" % (tag, k), atol=2 * lr * steps)
+
+
 @pytest.mark.parametrize("fname,iters", [("step3d_gan_s3.pt", 6), ("step3d_vae_s1.pt", 6)])
 def test_several_iterations_track_the_oracle(fname, iters):
     """Longer horizon than the reference fixtures hold: N consecutive iterations of the same stage (optimizer moments and
