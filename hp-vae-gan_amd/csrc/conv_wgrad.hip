@@ -250,6 +250,341 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward-weight of the 3x3x3 conv, second generation: ONE workgroup owns all 27 taps of a 64(o) x 32(c) block.
+// conv_wgrad_kernel gives each time tap its own workgroup, so a dY tile is staged by three workgroups and an X plane by
+// three (2.37 GB of HBM traffic per launch against 0.49 GB algorithmic, the sharing left to the L2 and to keeping the taps
+// in step) and the outer taps have less work than the centre one.  Here the sharing is structural:
+//   * a workgroup walks a contiguous range of the time-major tile list (spatial tile, then t): moving from t to t+1 it
+//     stages ONE new X plane (t+2) into a ring of four plane slots and the next dY tile, and runs 27 taps on them - a third
+//     of the staging instructions per MFMA; planes -1 and T are a shared row of zeros in LDS (no staging, no code variants);
+//   * 64 x 32 x 27 outputs = 54 accumulator tiles over 4 waves (one per SIMD, 512 registers each): wave (oblk, th) holds
+//     taps th*14 .. th*14+12 of its 32 output channels and HALF of the centre tap 13 (th = 0 takes the even K steps, th = 1
+//     the odd ones; the two halves are separate slab entries, summed by the reduce kernel) - 13.5 tiles each, no imbalance;
+//   * the partial slab is part[slot][z][28][64][32], summed in slot order by conv_wgrad3_reduce_kernel (reproducible).
+struct Wgrad3Args {
+  const float* dy;
+  const float* x;
+  float* part;
+  int B, Cin, Cout, T, H, W;
+  int Th, Tw, RS, DS, XS, QK, nth, ntw, S, ncb, nob;   // ncb: 32-channel blocks of Cin
+  int ntiles;                                          // B * nth * ntw * T
+};
+
+// One channel row of a staging stream by LDS-DMA, branch-free: `mask` (wave-uniform) switches off the lanes past the row
+// end through EXEC inside the statement, so the piece is straight-line code that fits in the shadow of ONE MFMA (a
+// compiler-generated `if (lane < n)` around the builtin is a saveexec + branch pair, and a staging piece with branches in
+// it only starts after the last MFMA in front of it has issued).  The compiler does not see the load: every barrier that
+// publishes staged data is preceded by an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void wg3_dma_row(const char* src, unsigned lds_addr, unsigned long long mask) {
+  unsigned long long keep_exec;
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b32 %1, m0\n\t"
+      "s_mov_b64 exec, %3\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %2, off\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(keep_exec), "=&s"(keep_m0)
+      : "v"(src), "s"(mask), "s"(lds_addr)
+      : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int oblk = wave & 1, th = wave >> 1;
+  // ids: channel-block pair fastest inside the contiguous id range an XCD owns, so the workgroups that stage the same dY
+  // tiles (same slot, other input-channel half) share that XCD's L2
+  const int nz = a.nob * a.ncb;
+  const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const int z = L % nz, slot = L / nz;
+  const int ob = z / a.ncb, cb = z % a.ncb;
+  const int RS = a.RS, DS = a.DS, XS = a.XS;
+  const long HW = (long)a.H * a.W;
+  const long cstride = (long)a.T * HW;
+  int no = a.Cout - ob * 64; if (no > 64) no = 64;   // channels present in this block
+  int nc = a.Cin - cb * 32;  if (nc > 32) nc = 32;
+  const bool active = oblk * 32 < no;
+
+  const int DYB = 0;                       // two dY tiles   [64][DS]        (offsets in floats)
+  const int XR = 2 * 64 * DS;              // four X planes  [32][XS]
+  const int ZR = XR + 4 * 32 * XS;         // XS zeros: the planes outside the clip
+  for (int i = tid; i < ZR + XS; i += 256) lds[i] = 0.f;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+
+  f32x16 acc[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+  // ---- staging streams of the tile being staged: dY (64 channel rows), X plane A, X plane B (32 rows each).  Per lane: a
+  // source pointer (the zero word for padded positions) and its per-channel byte stride (0 for padded positions); per
+  // wave: the EXEC mask of the lanes inside the row and the LDS byte address of this wave's 64-position piece of the row.
+  // A row past the block's last channel repeats that channel (finite data in a row whose outputs the reduce kernel drops).
+  auto rowmask = [&](int len) __attribute__((always_inline)) -> unsigned long long {
+    int n = len - wave * 64;
+    n = n < 0 ? 0 : (n > 64 ? 64 : n);
+    return n == 64 ? ~0ull : ((1ull << n) - 1ull);
+  };
+  const unsigned long long dmask = rowmask(DS), xmask = rowmask(XS);
+  const unsigned cbytes = (unsigned)(cstride * 4);
+  const char* dp;  unsigned dst;          // dY stream
+  const char* ap;  const char* bp; unsigned xst;   // planes A, B (same lane geometry)
+  unsigned d_lds = 0, a_lds = 0, b_lds = 0;        // LDS byte addresses of the next row
+  int d_row = 0, a_row = 0, b_row = 0;
+  auto setup = [&](int g, int pa, int pb) __attribute__((always_inline)) {
+    const int t = g % a.T;
+    int r = g / a.T;
+    const int tw_i = r % a.ntw;
+    r /= a.ntw;
+    const int th_i = r % a.nth;
+    const int b = r / a.nth;
+    const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
+    const float* dyp = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
+    const float* xp0 = a.x + ((long)b * a.Cin + cb * 32) * a.T * HW;
+    {
+      const int p = tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
+      dp = ok ? (const char*)(dyp + gh * a.W + gw) : (const char*)g_wzero;
+      dst = ok ? cbytes : 0u;
+    }
+    {
+      const int p = tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      const bool ok = hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const long off = (long)gh * a.W + gw;
+      ap = (ok && pa >= 0) ? (const char*)(xp0 + pa * HW + off) : (const char*)g_wzero;
+      bp = (ok && pb >= 0) ? (const char*)(xp0 + pb * HW + off) : (const char*)g_wzero;
+      xst = ok ? cbytes : 0u;
+    }
+    d_row = a_row = b_row = 0;
+  };
+#define W3_STAGE_D { wg3_dma_row(dp, d_lds, dmask); ++d_row; dp += (d_row < no ? dst : 0u); d_lds += DS * 4; }
+#define W3_STAGE_A { wg3_dma_row(ap, a_lds, xmask); ++a_row; ap += (a_row < nc ? xst : 0u); a_lds += XS * 4; }
+#define W3_STAGE_B { wg3_dma_row(bp, b_lds, xmask); ++b_row; bp += (b_row < nc ? xst : 0u); b_lds += XS * 4; }
+#define W3_STAGE_N {}
+
+  const int g_lo = (int)((long)slot * a.ntiles / a.S), g_hi = (int)((long)(slot + 1) * a.ntiles / a.S);
+  int ridx[3] = {-1, -1, -1};   // ring slots of the planes t-1, t, t+1 of the current tile (-1: outside the clip)
+  int cur = 0;
+  __syncthreads();  // zero fill done
+  if (g_lo < g_hi) {
+    // first tile of the range: everything at once (planes t and t+1 as A / B, then t-1 alone)
+    const int t = g_lo % a.T;
+    ridx[1] = 0;
+    ridx[2] = t + 1 < a.T ? 1 : -1;
+    ridx[0] = t > 0 ? 2 : -1;
+    setup(g_lo, t, t + 1 < a.T ? t + 1 : -1);
+    d_lds = lds0 + (DYB + wave * 64) * 4;
+    a_lds = lds0 + (XR + 0 * 32 * XS + wave * 64) * 4;
+    b_lds = lds0 + (XR + 1 * 32 * XS + wave * 64) * 4;
+#pragma unroll 1
+    for (int k = 0; k < 64; ++k) W3_STAGE_D
+#pragma unroll 1
+    for (int k = 0; k < 32; ++k) W3_STAGE_A
+    if (t + 1 < a.T) {
+#pragma unroll 1
+      for (int k = 0; k < 32; ++k) W3_STAGE_B
+    }
+    if (t > 0) {
+      setup(g_lo, t - 1, -1);
+      a_lds = lds0 + (XR + 2 * 32 * XS + wave * 64) * 4;
+#pragma unroll 1
+      for (int k = 0; k < 32; ++k) W3_STAGE_A
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMAs above are invisible to the compiler
+  __syncthreads();
+
+  const int nsteps = a.QK >> 2;  // K-loop iterations (4 positions = 2 MFMA k-steps each)
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int t = g % a.T;
+    int rows_d = 0, rows_a = 0, rows_b = 0;   // rows of the next tile's streams still to issue (multiples of 8)
+    int rnext[3] = {-1, -1, -1};
+    if (g + 1 < g_hi) {
+      // the two lowest ring slots not used by the current tile (it holds at most three of the four)
+      unsigned freem = 15u;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (ridx[d] >= 0) freem &= ~(1u << ridx[d]);
+      const int fr0 = __builtin_ctz(freem);
+      const int fr1 = __builtin_ctz((freem & (freem - 1u)) | 16u);
+      int pa = -1, pb = -1, sa = 0, sb = 0;
+      if (t + 1 < a.T) {           // same spatial tile, next plane: slide the window
+        rnext[0] = ridx[1];
+        rnext[1] = ridx[2];
+        if (t + 2 < a.T) { pa = t + 2; rnext[2] = fr0; sa = fr0; }
+      } else {                     // next spatial tile starts at t = 0: planes 0 and 1 (the current tile holds two slots)
+        pa = 0;
+        rnext[1] = fr0; sa = fr0;
+        if (a.T > 1) { pb = 1; rnext[2] = fr1; sb = fr1; }
+      }
+      setup(g + 1, pa, pb);
+      d_lds = lds0 + (DYB + (cur ^ 1) * 64 * DS + wave * 64) * 4;
+      a_lds = lds0 + (XR + sa * 32 * XS + wave * 64) * 4;
+      b_lds = lds0 + (XR + sb * 32 * XS + wave * 64) * 4;
+      rows_d = 64;
+      rows_a = pa >= 0 ? 32 : 0;
+      rows_b = pb >= 0 ? 32 : 0;
+    }
+    if (active) {
+      // LDS offsets (in floats) of this lane's operand rows.  One code path for both tap halves: the 13 taps of a wave are
+      // a table of per-lane offsets (plane of the tap's dt, row dh, column dw), picked by th once per tile.
+      const int dlo = DYB + cur * 64 * DS + (oblk * 32 + l31) * DS + half;
+      const int zo = ZR + half;
+      const int xb0 = ridx[0] >= 0 ? XR + ridx[0] * 32 * XS + l31 * XS + half : zo;
+      const int xb1 = ridx[1] >= 0 ? XR + ridx[1] * 32 * XS + l31 * XS + half : zo;
+      const int xb2 = ridx[2] >= 0 ? XR + ridx[2] * 32 * XS + l31 * XS + half : zo;
+#define W3_TAPOFS(TAP) (((TAP) / 9 == 0 ? xb0 : ((TAP) / 9 == 1 ? xb1 : xb2)) + (((TAP) % 9) / 3) * RS + (TAP) % 3)
+      int xo[13];
+#pragma unroll
+      for (int k = 0; k < 13; ++k) xo[k] = th == 0 ? W3_TAPOFS(k) : W3_TAPOFS(14 + k);
+#undef W3_TAPOFS
+      const int xso = xb1 + RS + 1 + th * 4;   // the shared centre tap: th = 0 takes the even K steps, th = 1 the odd ones
+      const int dso = dlo + th * 4;
+      // two register sets: the LDS reads of step st+1 are issued before the MFMAs of step st (1 wave per SIMD: nothing
+      // else hides the ds_read latency).  Set p runs the even steps, set q the odd ones; the centre tap's half (acc[13])
+      // rides with p: its operands sa / sb are those of step st + th.
+      float pa0, pa1, pb0[13], pb1[13], qa0, qa1, qb0[13], qb1[13], sa0, sa1, sb0, sb1;
+#define W3_LOAD(A0, A1, B0, B1, ST)                                   \
+  {                                                                   \
+    const int q0_ = (ST) * 4;                                         \
+    A0 = lds[dlo + q0_];                                              \
+    A1 = lds[dlo + q0_ + 2];                                          \
+    _Pragma("unroll") for (int k = 0; k < 13; ++k) {                  \
+      B0[k] = lds[xo[k] + q0_];                                       \
+      B1[k] = lds[xo[k] + q0_ + 2];                                   \
+    }                                                                 \
+  }
+#define W3_LOADS(ST)                                                  \
+  {                                                                   \
+    const int q0_ = (ST) * 4;                                         \
+    sa0 = lds[dso + q0_];                                             \
+    sa1 = lds[dso + q0_ + 2];                                         \
+    sb0 = lds[xso + q0_];                                             \
+    sb1 = lds[xso + q0_ + 2];                                         \
+  }
+// 26 (28) MFMAs with four rows of DMA staging between them (each row piece is straight-line: one MFMA's shadow)
+#define W3_MMA(A0, A1, B0, B1, SH, STG)                                                                             \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0[k], acc[k], 0, 0, 0);  \
+    STG                                                                                                             \
+    _Pragma("unroll") for (int k = 4; k < 13; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0[k], acc[k], 0, 0, 0); \
+    if (SH) acc[13] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa0, sb0, acc[13], 0, 0, 0);                             \
+    STG                                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[k], acc[k], 0, 0, 0);  \
+    STG                                                                                                             \
+    _Pragma("unroll") for (int k = 4; k < 13; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[k], acc[k], 0, 0, 0); \
+    if (SH) acc[13] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa1, sb1, acc[13], 0, 0, 0);                             \
+    STG                                                                                                             \
+  }
+// two K steps (sets p and q) with eight rows of one staging stream
+#define W3_BODY(STG)                                                                    \
+  {                                                                                     \
+    W3_LOAD(qa0, qa1, qb0, qb1, st + 1);                                                \
+    W3_MMA(pa0, pa1, pb0, pb1, true, STG);                                              \
+    if (st + 2 < nsteps) { W3_LOAD(pa0, pa1, pb0, pb1, st + 2); W3_LOADS(st + 2); }     \
+    W3_MMA(qa0, qa1, qb0, qb1, false, STG);                                             \
+  }
+      int st = 0;
+      if (st < nsteps) { W3_LOAD(pa0, pa1, pb0, pb1, st); W3_LOADS(st); }
+      // the K loop in phases, one per staging stream (the stream is then compile-time in the loop body)
+      for (; st + 1 < nsteps && rows_d > 0; st += 2, rows_d -= 8) W3_BODY(W3_STAGE_D)
+      for (; st + 1 < nsteps && rows_a > 0; st += 2, rows_a -= 8) W3_BODY(W3_STAGE_A)
+      for (; st + 1 < nsteps && rows_b > 0; st += 2, rows_b -= 8) W3_BODY(W3_STAGE_B)
+      for (; st + 1 < nsteps; st += 2) W3_BODY(W3_STAGE_N)
+      if (st < nsteps) {
+        // odd step count: the last step is an even one - th = 0's half of the centre tap; th = 1's would be step nsteps
+        W3_MMA(pa0, pa1, pb0, pb1, false, W3_STAGE_N);
+        if (th == 0) {
+          acc[13] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa0, sb0, acc[13], 0, 0, 0);
+          acc[13] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa1, sb1, acc[13], 0, 0, 0);
+        }
+      }
+#undef W3_BODY
+#undef W3_MMA
+#undef W3_LOADS
+#undef W3_LOAD
+    }
+    // whatever did not fit into the K loop (short loops, idle waves)
+#pragma unroll 1
+    for (; rows_d > 0; --rows_d) W3_STAGE_D
+#pragma unroll 1
+    for (; rows_a > 0; --rows_a) W3_STAGE_A
+#pragma unroll 1
+    for (; rows_b > 0; --rows_b) W3_STAGE_B
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): next tile landed (this wave's share) ...
+    __syncthreads();                     // ... everybody's has, and the current buffers are free
+    cur ^= 1;
+    ridx[0] = rnext[0]; ridx[1] = rnext[1]; ridx[2] = rnext[2];
+  }
+#undef W3_STAGE_D
+#undef W3_STAGE_A
+#undef W3_STAGE_B
+#undef W3_STAGE_N
+
+  // ---- partial slab: part[slot][z][28][o64][c32]; entry th*14 + k = tap th*14 + k (k < 13), entries 13 / 27 = the two
+  // halves of the centre tap
+  float* pp = a.part + ((long)slot * nz + z) * 28 * 2048;
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    const int entry = k < 13 ? th * 14 + k : (th == 0 ? 13 : 27);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = oblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      pp[(long)entry * 2048 + row * 32 + l31] = active ? acc[k][e] : 0.f;
+    }
+  }
+}
+
+// dW[o][c][tap27] = sum_slot part[slot][z][tap][o%64][c%32] (+ the second half of the centre tap); one thread per
+// element, slots in order (reproducible)
+__global__ void conv_wgrad3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int nob, int ncb, int Cout,
+                                          int Cin, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nz = nob * ncb;
+  const long total = (long)nz * 27 * 2048;
+  if (idx >= total) return;
+  long r = idx;
+  const int c32 = r % 32; r /= 32;
+  const int o64 = r % 64; r /= 64;
+  const int tap = r % 27; r /= 27;
+  const int z = (int)r;
+  const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 32 + c32;
+  if (o >= Cout || c >= Cin) return;
+  const long per_s = (long)nz * 28 * 2048;
+  const float* p0 = part + ((long)z * 28 + tap) * 2048 + o64 * 32 + c32;
+  float s0 = 0.f, s1 = 0.f;
+  if (tap == 13) {
+    for (int s = 0; s < S; ++s) {
+      s0 += p0[(long)s * per_s];
+      s1 += p0[(long)s * per_s + 14 * 2048];
+    }
+  } else {
+    int s = 0;
+    for (; s + 2 <= S; s += 2) {
+      s0 += p0[(long)s * per_s];
+      s1 += p0[(long)(s + 1) * per_s];
+    }
+    if (s < S) s0 += p0[(long)s * per_s];
+  }
+  const float tot = s0 + s1;
+  float* dst = dw + ((long)o * Cin + c) * 27 + tap;
+  *dst = accumulate ? *dst + tot : tot;
+}
+
+// ------------------------------------------------------------------------------------------
 // Narrow backward-weight: one side of the layer has <= 4 channels (heads 3->64, tails 64->3 / 64->1).
 //   R[cw][cn][tap] = sum_pos wide[cw][pos] * narrow[cn][pos + off(tap)]          (all KT*9 taps at once)
 // head (Cin <= 4):  wide = dY (Cout ch), narrow = X          ->  dW[o=cw][c=cn][tap]        = R
@@ -767,6 +1102,62 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   return plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
 }
 
+// tile plan of conv_wgrad3_kernel: the same tile family as conv_wgrad_kernel under its own LDS budget (two dY tiles, four
+// 32-channel X planes, one row of zeros); S persistent workgroups per (64 output, 32 input channel) block pair
+struct W3Plan { int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb; size_t lds; long ntiles; bool ok; };
+W3Plan plan_wgrad3(int B, int Cin, int Cout, int T, int H, int W) {
+  struct Key { int B, Cin, Cout, T, H, W; };
+  struct Entry { Key k; W3Plan p; };
+  constexpr int NE = 256;
+  static thread_local Entry cache[NE];
+  static thread_local int filled = 0;
+  for (int i = 0; i < filled; ++i) {
+    const Key& c = cache[i].k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W) return cache[i].p;
+  }
+  W3Plan best{};
+  double best_cost = 1e300;
+  for (int Tw = 1; Tw <= W; ++Tw) {
+    const int ntw = hpvg_cdiv(W, Tw);
+    if (Tw != hpvg_cdiv(W, ntw)) continue;
+    const int RS = Tw + 2;
+    for (int Th = 1; Th <= H; ++Th) {
+      const int nth = hpvg_cdiv(H, Th);
+      if (Th != hpvg_cdiv(H, nth)) continue;
+      const int QK = (Th * RS + 3) & ~3;                 // K positions, padded to the 4-position loop step
+      const int DS = (QK + 1) | 1;                       // dY row stride: >= QK, odd (bank spread)
+      int XS = QK + 2 * RS + 4;                          // X row: reads reach QK-1 + 2*RS + 2
+      if (XS < (Th + 2) * RS + 1) XS = (Th + 2) * RS + 1;
+      XS |= 1;
+      if (DS > 256 || XS > 256) break;                   // one 256-lane DMA round per row
+      const size_t lds = ((size_t)2 * 64 * DS + (size_t)4 * 32 * XS + XS) * sizeof(float);
+      if (lds > 158 * 1024) break;
+      const long nsp = (long)B * nth * ntw;
+      const double work = (double)nsp * T * (QK * 0.5 * 27.0 + 80.0);   // MFMAs of the K loop + per-tile fixed cost
+      if (work < best_cost) {
+        best_cost = work;
+        best = W3Plan{Th, Tw, RS, DS, XS, QK, nth, ntw, 0, hpvg_cdiv(Cout, 64), hpvg_cdiv(Cin, 32), lds, nsp * T, true};
+      }
+    }
+  }
+  if (best.ok) {
+    long cap = (long)HPVG_NUM_CU / ((long)best.nob * best.ncb);  // one persistent workgroup per CU
+    if (cap < 1) cap = 1;
+    best.S = (int)(best.ntiles < cap ? best.ntiles : cap);
+  }
+  if (filled < NE) cache[filled++] = Entry{Key{B, Cin, Cout, T, H, W}, best};
+  return best;
+}
+inline size_t wgrad3_ws_bytes(const W3Plan& q) { return 256 + (size_t)q.S * q.nob * q.ncb * 28 * 2048 * sizeof(float); }
+// conv_wgrad3_kernel pays off where a workgroup walks many tiles (its tiles carry three times the work, its slab is 1.5x
+// the size): measured on MI355X (tools/perf_conv.py, 64 -> 64) it wins 3-4 % at 78 and 156 tiles per workgroup (stage 9,
+// B = 2 / 4) and loses 2-5 % at 50 and below (stages <= 8).  HPVG_WGRAD3: 0 = never, 2 = always (tests), default = by size.
+static const int g_wgrad3_mode = [] { const char* e = getenv("HPVG_WGRAD3"); return e ? atoi(e) : 1; }();
+inline bool wgrad3_wanted(const W3Plan& q) {
+  if (!q.ok || g_wgrad3_mode == 0) return false;
+  return g_wgrad3_mode == 2 || q.ntiles >= 64L * q.S;
+}
+
 // narrow path selection: 0 = head (Cin <= 4), 1 = tail (Cout <= 4), -1 = full kernel
 inline int narrow_mode(int Cin, int Cout) {
   if (Cin <= 4 && Cout > 4) return 0;
@@ -819,7 +1210,12 @@ size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);
   const int nm = narrow_mode(Cin, Cout);
   if (nm >= 0) return narrow_ws_bytes(p, nm == 0 ? Cout : Cin, nm == 0 ? Cin : Cout, KT, (long)B * T * p.nth * p.ntw);
-  return 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+  size_t need = 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
+  if (KT == 3) {
+    const W3Plan q = plan_wgrad3(B, Cin, Cout, T, H, W);
+    if (wgrad3_wanted(q) && wgrad3_ws_bytes(q) > need) need = wgrad3_ws_bytes(q);
+  }
+  return need;
 }
 
 // dw: natural layout [Cout][Cin][KT][3][3]; accumulate != 0 adds into dw instead of overwriting.
@@ -908,10 +1304,40 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
                        (int)S * 4, nwb, NT, CW, CN, KT * 9, nm, accumulate);
     return hpvg_launch_status();
   }
+  if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
+  if (KT == 3) {
+    const W3Plan q = plan_wgrad3(B, Cin, Cout, T, H, W);
+    if (wgrad3_wanted(q)) {
+      // ---- all 27 taps in one workgroup (conv_wgrad3_kernel)
+      if (ws_bytes < wgrad3_ws_bytes(q)) return HPVG_ERR_WORKSPACE;
+      Wgrad3Args w3;
+      w3.dy = dy; w3.x = x; w3.part = (float*)((char*)ws + 256);
+      w3.B = B; w3.Cin = Cin; w3.Cout = Cout; w3.T = T; w3.H = H; w3.W = W;
+      w3.Th = q.Th; w3.Tw = q.Tw; w3.RS = q.RS; w3.DS = q.DS; w3.XS = q.XS; w3.QK = q.QK; w3.nth = q.nth; w3.ntw = q.ntw;
+      w3.S = q.S; w3.ncb = q.ncb; w3.nob = q.nob; w3.ntiles = (int)q.ntiles;
+      hipStream_t s3 = (hipStream_t)stream;
+      const dim3 grid3((unsigned)(q.S * q.nob * q.ncb));
+      {
+        static bool attr = false;
+        if (!attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+          attr = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad3_kernel, grid3, dim3(256), q.lds, s3, w3);
+      }
+      int st3 = hpvg_launch_status();
+      if (st3 != HPVG_OK) return st3;
+      const long total3 = (long)q.nob * q.ncb * 27 * 2048;
+      hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(hpvg_cdiv(total3, 256)), dim3(256), 0, s3, (const float*)w3.part, dw, q.S,
+                         q.nob, q.ncb, Cout, Cin, accumulate);
+      return hpvg_launch_status();
+    }
+  }
   const size_t need = 256 + (size_t)p.S * KT * p.nob * p.ncb * 9 * 4096 * sizeof(float);
   if (ws_bytes < need) return HPVG_ERR_WORKSPACE;
   WgradArgs a;
-  if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
   a.dy = dy; a.x = x; a.in_scale = in_scale; a.in_shift = in_shift;
   a.part = (float*)((char*)ws + 256);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;

@@ -637,3 +637,17 @@ def test_device_noise_kernel(ops):
     assert_close(up, plain, 1e-6, "fused resize")                          # (two kernels: fma contraction may differ in the last bit)
     assert torch.equal(upn[:2], up[:2])                                     # the rec half of a merged pass gets no noise
     assert_close(upn[2:], plain[2:] + 0.37 * nz[2:], 1e-6, "fused level noise")
+
+
+def test_wgrad_all_taps_kernel_on_small_shapes():
+    """conv_wgrad3_kernel (all 27 taps of a 64 x 32 channel block in one workgroup, sliding window over t) is picked by size
+    (>= 64 tiles per workgroup: the BASELINE stage-9 shapes, covered by test_full_size_conv_family_properties); here a child
+    process forces it (HPVG_WGRAD3=2, read once at library load) onto odd small shapes against the oracle."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HPVG_WGRAD3="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "wgrad3_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "wgrad3 ok" in r.stdout

@@ -10,7 +10,7 @@ SHAPES = {0: (4, 18, 33), 1: (4, 23, 41), 2: (4, 29, 52), 3: (5, 36, 65), 4: (5,
 stage = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 T, H, W = SHAPES[stage]
-B = 2
+B = int(os.environ.get("HPVG_PERF_B", "2"))
 dev = "cuda"
 torch.manual_seed(0)
 x = torch.randn(B, 64, T, H, W, device=dev)
