@@ -548,40 +548,50 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Args a)
   }
 }
 
-// dW[o][c][tap27] = sum_slot part[slot][z][tap][o%64][c%32] (+ the second half of the centre tap); one thread per
-// element, slots in order (reproducible)
-__global__ void conv_wgrad3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int nob, int ncb, int Cout,
-                                          int Cin, int accumulate) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// dW[o][c][tap27] = sum_slot part[slot][z][tap][o%64][c%32] (+ the second half of the centre tap).  A block is 256 elements
+// x 4 slot groups (group g sums the slots [g*S/4, (g+1)*S/4) in order, two chains), the four group sums are added in
+// group order through LDS: reproducible, and four times the loads in flight of a one-thread-per-element loop (128 slabs a
+// quarter of a megabyte apart: that loop was latency-bound at 1.5 TB/s).
+__global__ __launch_bounds__(1024) void conv_wgrad3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S,
+                                                                  int nob, int ncb, int Cout, int Cin, int accumulate) {
+  __shared__ float sm[4][256];
+  const int g = threadIdx.y;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int nz = nob * ncb;
   const long total = (long)nz * 27 * 2048;
-  if (idx >= total) return;
-  long r = idx;
+  long r = idx < total ? idx : total - 1;
   const int c32 = r % 32; r /= 32;
   const int o64 = r % 64; r /= 64;
   const int tap = r % 27; r /= 27;
   const int z = (int)r;
   const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 32 + c32;
-  if (o >= Cout || c >= Cin) return;
+  const bool live = idx < total && o < Cout && c < Cin;
   const long per_s = (long)nz * 28 * 2048;
   const float* p0 = part + ((long)z * 28 + tap) * 2048 + o64 * 32 + c32;
   float s0 = 0.f, s1 = 0.f;
-  if (tap == 13) {
-    for (int s = 0; s < S; ++s) {
-      s0 += p0[(long)s * per_s];
-      s1 += p0[(long)s * per_s + 14 * 2048];
+  if (live) {
+    int sl = (int)((long)g * S / 4);
+    const int hi = (int)((long)(g + 1) * S / 4);
+    if (tap == 13) {
+      for (; sl < hi; ++sl) {
+        s0 += p0[(long)sl * per_s];
+        s1 += p0[(long)sl * per_s + 14 * 2048];
+      }
+    } else {
+      for (; sl + 2 <= hi; sl += 2) {
+        s0 += p0[(long)sl * per_s];
+        s1 += p0[(long)(sl + 1) * per_s];
+      }
+      if (sl < hi) s0 += p0[(long)sl * per_s];
     }
-  } else {
-    int s = 0;
-    for (; s + 2 <= S; s += 2) {
-      s0 += p0[(long)s * per_s];
-      s1 += p0[(long)(s + 1) * per_s];
-    }
-    if (s < S) s0 += p0[(long)s * per_s];
   }
-  const float tot = s0 + s1;
-  float* dst = dw + ((long)o * Cin + c) * 27 + tap;
-  *dst = accumulate ? *dst + tot : tot;
+  sm[g][threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && live) {
+    const float tot = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    float* dst = dw + ((long)o * Cin + c) * 27 + tap;
+    *dst = accumulate ? *dst + tot : tot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1330,7 +1340,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
       int st3 = hpvg_launch_status();
       if (st3 != HPVG_OK) return st3;
       const long total3 = (long)q.nob * q.ncb * 27 * 2048;
-      hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(hpvg_cdiv(total3, 256)), dim3(256), 0, s3, (const float*)w3.part, dw, q.S,
+      hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(hpvg_cdiv(total3, 256)), dim3(256, 4), 0, s3, (const float*)w3.part, dw, q.S,
                          q.nob, q.ncb, Cout, Cin, accumulate);
       return hpvg_launch_status();
     }
