@@ -119,6 +119,7 @@ struct StageSlots {
   int gofs[NJMAX];        // element offset inside a (c,t) plane (valid lanes)
   unsigned bofs[NJMAX];   // the same in bytes (planes are < 4 GB)
   unsigned okmask, wmask; // bit j: slot j lies inside the image / inside the staged plane
+  unsigned long long em[NJMAX];  // EXEC mask of the lanes whose slot j lies inside the image (wave-uniform)
 };
 __device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int q0, int w0, int tid) {
   // slot p holds position P = q0 + p of the zero-padded, row-flattened band: row P / RS - 1, column w0 + P % RS - 1
@@ -142,8 +143,33 @@ __device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int
         sl.bofs[j] = (unsigned)sl.gofs[j] * 4u;
       }
     }
+    sl.em[j] = __ballot((sl.okmask >> j) & 1u);
   }
   return sl;
+}
+
+#ifndef HPVG_CONV_ASM_STAGE
+#define HPVG_CONV_ASM_STAGE 1
+#endif
+// One LDS-DMA piece of the staging loop as straight-line code: scalar plane base + per-lane byte offset (no address
+// VALU), the out-of-image lanes switched off through EXEC inside the statement (the builtin under `if (lane ok)` is a
+// saveexec + taken branch + a 64-bit VALU add per piece).  Invisible to the compiler: the barrier that publishes the chunk is
+// preceded by an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void conv_dma_piece(const char* base, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+  unsigned long long keep_exec;
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b32 %1, m0\n\t"
+      "s_mov_b64 exec, %3\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %2, %5\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(keep_exec), "=&s"(keep_m0)
+      : "v"(voff), "s"(mask), "s"(lds_addr), "s"(base)
+      : "memory");
 }
 
 // Stage channel chunk `ch` (CC channels x KT time planes) of the tile of sample b / output plane t into xs.
@@ -168,10 +194,17 @@ __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs
       float* dst = xs + pl * PL + wave * 64;
       if (valid) {
         const char* src = reinterpret_cast<const char*>(a.x + (((long)b * a.Cin + cg) * a.T + tt) * HW);
+#if HPVG_CONV_ASM_STAGE
+        const unsigned dst_lds = (unsigned)(size_t)(lptr_t)dst;
+#pragma unroll
+        for (int j = 0; j < NJMAX; ++j)
+          if (sl.em[j] != 0ull) conv_dma_piece(src, sl.bofs[j], dst_lds + j * 1024, sl.em[j]);
+#else
 #pragma unroll
         for (int j = 0; j < NJMAX; ++j)
           if ((sl.okmask >> j) & 1u)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + sl.bofs[j]), (lptr_t)(dst + j * 256), 4, 0, 0);
+#endif
         if (first_chunk) {
 #pragma unroll
           for (int j = 0; j < NJMAX; ++j)
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       conv_stage_chunk<CC, KT, VAR == VAR_PRO>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
       HPVG_PH(0)
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the asm LDS-DMA pieces are invisible to the compiler's counters
       __syncthreads();
       HPVG_PH(1)
 
