@@ -185,15 +185,21 @@ __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs
     // VALU port busy, which stretched a select-per-load version of this loop from 2.4 to 15-20 us per chunk): the
     // per-lane byte offsets are tile constants, the plane base is scalar, out-of-image lanes are switched off by
     // EXEC and their LDS words are zeroed once per tile (no load ever writes them).
+    // plane pointers advance by scalar adds (recomputing ((b*Cin + c)*T + t)*HW per plane is ~15 scalar instructions of
+    // 64-bit multiply in a loop whose pieces cost ~8)
+    const long HWb = HW * 4;
+    const char* cbase = reinterpret_cast<const char*>(a.x) + (((long)b * a.Cin + (long)ch * CC) * a.T + (t - (KT == 3 ? 1 : 0))) * HWb;
+    int pl = 0;
 #pragma unroll 1
-    for (int pl = 0; pl < CC * KT; ++pl) {
-      const int c = pl / KT, dt = pl - c * KT;
+    for (int c = 0; c < CC; ++c, cbase += (long)a.T * HWb)
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt, ++pl) {
       const int cg = ch * CC + c;
       const int tt = t + dt - (KT == 3 ? 1 : 0);
       const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
       float* dst = xs + pl * PL + wave * 64;
       if (valid) {
-        const char* src = reinterpret_cast<const char*>(a.x + (((long)b * a.Cin + cg) * a.T + tt) * HW);
+        const char* src = cbase + dt * HWb;
 #if HPVG_CONV_ASM_STAGE
         const unsigned dst_lds = (unsigned)(size_t)(lptr_t)dst;
 #pragma unroll
