@@ -980,10 +980,11 @@ inline long conv_slots(int MB, int NB) { return (long)HPVG_CONV_WGS(MB, NB) * HP
 // Tile planner.  streamk = true: the launch is S = min(items, 512) persistent workgroups that share the (tile, chunk)
 // items evenly (needs the partial-slab workspace).  streamk = false: one workgroup per tile, dealt out by the
 // hardware dispatcher (no workspace; grids of 1-5 tiles per slot are quantised - the reason stream-K exists).
-// Cost in us; constants fitted to measured launches (tools/perf_conv.py, stages 5-9, within 5 %): an item costs its
+// Cost in us; constants chosen to minimise the REGRET of the plan picked over the measured landscapes of stages 3-9 at
+// B = 2 and 4 (tools/ab_conv_plan.sh: every band count x NB forced; mean regret 0.3 %, worst 1.6 %): an item costs its
 // MFMA rounds (6.5 us per 32-position x 32-channel x 8-channel-chunk round when two workgroups share the CU's matrix
-// pipe, half that when alone) + ~8 us of staging / barrier work the co-resident workgroup does not hide + the input
-// planes it stages; tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block,
+// pipe, half that when alone) + ~6 us of staging / barrier work the co-resident workgroup does not hide (2 when alone)
+// + the input planes it stages (2 us per 1000 positions); tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block,
 // written by the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth).
 Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk, bool narrow) {
   const int CC = conv_cc(Cin);
@@ -1064,13 +1065,13 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
         const size_t lds = (size_t)CC * KT * PL * sizeof(float);
         if (lds > (HPVG_CONV_WGS(MB, NB) == 4 ? 38 : 80) * 1024) continue;
         const long ntl = (long)B * T * nrange * ntw * gridy;
-        const double stage_us = 0.0065 * plload;
+        const double stage_us = 0.002 * plload;
         double cost;
         if (streamk) {
           // S co-resident workgroups share the (tile, chunk) items evenly.  Cost in us, constants fitted to measured
           // launches (tools/perf_conv.py, stages 5-9, within 5 %): an item costs its MFMA rounds (6.5 us per 32-position
           // x 32-channel x 8-channel-chunk round when two workgroups share the CU's matrix pipe, half that when alone)
-          // + ~8 us of staging / barrier work the co-resident workgroup does not hide + the input planes it stages;
+          // + ~6 us of staging / barrier work the co-resident workgroup does not hide + the input planes it stages;
           // tiles cut across workgroups travel through HBM as raw accumulator slabs (16 KB per 32x32 block, written by
           // the main kernel, read back by the fix-up: ~5.5 us per block at the chip's share of bandwidth)
           const long items_tot = ntl * nchunk;
@@ -1080,19 +1081,19 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
           const long rem = (ntl - ndp * S) * nchunk;
           const double items = (double)(ndp * nchunk) + (double)((rem + S - 1) / S);
           const bool paired = S > HPVG_NUM_CU;
-          const double per_item = (double)NB * MB * (paired ? 6.5 : 3.4) + (paired ? 8.5 : 6.0) + stage_us;
+          const double per_item = (double)NB * MB * (paired ? 6.5 : 3.0) + (paired ? 6.0 : 2.0) + stage_us;
           const double tiles = (double)(ndp + (rem ? 1 : 0));
           double parts = 0.0;
           if (rem) {
             parts = 1.0 + (double)rem / (double)S / (double)nchunk;
             if (parts > 2.0) parts = 2.0;
           }
-          cost = items * per_item + tiles * 0.8 * NB * MB + parts * 5.5 * NB * MB + 1e-4 * (double)ntl;
+          cost = items * per_item + tiles * 0.4 * NB * MB + parts * 5.5 * NB * MB + 1e-4 * (double)ntl;
         } else {
           // one workgroup per tile: whole tiles per CU, pairs run together, an odd one runs alone at the end
           const long per_cu = (ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
-          const double tile_paired = nchunk * ((double)NB * MB * 6.5 + 8.5 + stage_us) + 0.8 * NB * MB;
-          const double tile_alone = nchunk * ((double)NB * MB * 3.4 + 6.0 + stage_us) + 0.8 * NB * MB;
+          const double tile_paired = nchunk * ((double)NB * MB * 6.5 + 6.0 + stage_us) + 0.4 * NB * MB;
+          const double tile_alone = nchunk * ((double)NB * MB * 3.0 + 2.0 + stage_us) + 0.4 * NB * MB;
           cost = (double)(per_cu / 2) * tile_paired + (double)(per_cu & 1) * tile_alone + 1e-4 * (double)ntl;
         }
         if (cost < best_cost - 1e-9) {
