@@ -155,7 +155,13 @@ __device__ __forceinline__ StageSlots conv_stage_slots(const ConvFwdArgs& a, int
 // VALU), the out-of-image lanes switched off through EXEC inside the statement (the builtin under `if (lane ok)` is a
 // saveexec + taken branch + a 64-bit VALU add per piece).  Invisible to the compiler: the barrier that publishes the chunk is
 // preceded by an explicit s_waitcnt vmcnt(0).
-__device__ __forceinline__ void conv_dma_piece(const char* base, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+__device__ __forceinline__ void conv_dma_piece(const char* base_, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+  // the base IS wave-uniform, but under SGPR pressure hipcc may keep it in VGPRs and then hands the asm statement a VGPR
+  // pair for its "s" operand (an assembler error at best): rebuild it from two readfirstlanes so that its definition is scalar
+  const unsigned long long bb = (unsigned long long)base_;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);            // (the builtin returns int:
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32));    //  no sign extension, please)
+  const unsigned long long base = (unsigned long long)lo | ((unsigned long long)hi << 32);
   unsigned long long keep_exec;
   unsigned keep_m0;
   asm volatile(
