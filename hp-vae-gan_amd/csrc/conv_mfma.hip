@@ -533,6 +533,8 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
   }
 }
 
+#include "conv_wino.inl"
+
 // ------------------------------------------------------------------------------------------
 // Narrow-output convolution (Cout <= 4): the tails 64->3 / 64->1 (networks_3d.py:175,341,362) and the backward-data
 // pass of the 3->64 heads.  With output channels as the GEMM's M these waste >= 90 % of every 32-row tile (1.07 ms at
@@ -916,11 +918,19 @@ __global__ void conv_pack_narrow_kernel(const float* __restrict__ w, const float
 //   wp[chunk][tap][mblock][lane][cp] = Wsrc[o = mblock*32 + (lane&31)][c = chunk*CC + 2cp + (lane>>5)][tap]
 // transpose_flip=1 packs the backward-data weights (Wsrc[o'][c'][tap] = W[c'][o'][ntaps-1-tap]).
 // A device scalar `inv_scale` (1/sigma of spectral norm) is folded in when given.
+// Behind the direct pack (`total_direct` floats) follow the Winograd U fragments of the same weight when the layer is wide
+// enough for conv_wino_kernel (conv_wino.inl); which of the two a launch reads is decided per shape in conv_fwd_impl.
 __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale, float* __restrict__ wp,
                                  int Cin_k, int Cout_k, int taps, int CC, int nchunk, int mbtot, int transpose_flip,
-                                 long total) {
+                                 long total_direct, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
+  if (idx >= total_direct) {
+    float val = wino_pack_value(w, idx - total_direct, Cin_k, Cout_k, taps / 9, (Cin_k + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip);
+    if (inv_scale) val *= inv_scale[0];
+    wp[idx] = val;
+    return;
+  }
   const int CP = CC / 2;
   long r = idx;
   const int cp = r % CP; r /= CP;
@@ -947,13 +957,18 @@ struct PackBatchArgs {
   float* wp[HPVG_PACK_BATCH_MAX];
   int flip[HPVG_PACK_BATCH_MAX];
 };
-__global__ void conv_pack_batch_kernel(const PackBatchArgs a, int C, int taps, int CC, int nchunk, int mbtot, long total) {
+__global__ void conv_pack_batch_kernel(const PackBatchArgs a, int C, int taps, int CC, int nchunk, int mbtot, long total_direct,
+                                       long total) {
   // square layers only (Cin == Cout == C): the forward and the flipped pack then share every size
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int it = blockIdx.y;
   const float* __restrict__ w = a.w[it];
   const int transpose_flip = a.flip[it];
+  if (idx >= total_direct) {
+    a.wp[it][idx] = wino_pack_value(w, idx - total_direct, C, C, taps / 9, (C + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip);
+    return;
+  }
   const int CP = CC / 2;
   long r = idx;
   const int cp = r % CP; r /= CP;
@@ -974,6 +989,15 @@ __global__ void conv_pack_batch_kernel(const PackBatchArgs a, int C, int taps, i
 }
 
 inline int conv_cc(int Cin) { return Cin <= 4 ? 4 : 8; }
+
+// floats of the direct kernel's A-fragment pack (the Winograd fragments, when the layer has them, follow it)
+inline size_t direct_pack_floats(int Cin, int Cout, int KT) {
+  const int CC = conv_cc(Cin);
+  const int nchunk = hpvg_cdiv(Cin, CC);
+  const int mbtot = hpvg_cdiv(Cout, 32);
+  const size_t per_tap = (size_t)mbtot * 64 * (CC / 2);
+  return ((size_t)nchunk * KT * 9 + 2) * per_tap;  // +2 taps of zero tail padding (A prefetch runs one tap / one m-tile ahead)
+}
 
 struct Plan {
   int Th, Tw, RS, PL, L, qstride, nrange, ntw, nblocks, NB, MB, gridy, nj;  // Th != 0 only for the narrow kernel's 2-D tiles
@@ -1112,10 +1136,89 @@ Plan plan_conv_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
   return best;
 }
 
+// Tile plan of conv_wino_kernel: bands of an EVEN width Tw (row stride RS = Tw + 2 even: an output pair never straddles a
+// row), a band plane cut into balanced ranges of an even L <= NBP*128 positions (NBP*64 pairs).  Same cost form as above
+// with the Winograd item: 36 instead of 27 MFMA k-steps per channel pair on half the positions per accumulator set.
+Plan plan_wino_search(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
+  const int nchunk = hpvg_cdiv(Cin, WINO_CC);
+  const int mbtot = hpvg_cdiv(Cout, 32);
+  const int gridy = hpvg_cdiv(mbtot, 2);
+  static const int only_ntw = [] { const char* e = getenv("HPVG_PLAN_NTW"); return e ? atoi(e) : 0; }();
+  Plan best{};
+  double best_cost = 1e300;
+  const int Lmax = WINO_NBP * 128;
+  int prev_tw = 0;
+  for (int ntw = 1; ntw <= W; ++ntw) {
+    int Tw = hpvg_cdiv(W, ntw);
+    Tw += Tw & 1;
+    if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;  // same band width as before / an empty last band
+    prev_tw = Tw;
+    if (only_ntw && ntw != only_ntw) continue;
+    const int RS = Tw + 2;
+    const long flat = (long)(H - 1) * RS + Tw;
+    const int nrange = hpvg_cdiv(flat, Lmax);
+    int L = hpvg_cdiv(flat, nrange);
+    L += L & 1;
+    const int plload = L + 2 * RS + 2;
+    if (plload > NJMAX * 256) continue;
+    const int PL = Lmax + 2 * RS + 2;   // even; lanes past L still read (junk) operands inside the buffer
+    const size_t lds = (size_t)WINO_CC * KT * PL * sizeof(float);
+    if (lds > 80 * 1024) continue;
+    const long ntl = (long)B * T * nrange * ntw * gridy;
+    const double stage_us = 0.002 * plload;
+    const double mfma_paired = 6.5 * (2.0 * WINO_NBP) * (2.0 / 3.0);  // 64 ch x NBP*64 pairs = 2*NBP direct 32x32 block pairs, at 36/54 of their k-steps
+    double cost;
+    if (streamk) {
+      const long items_tot = ntl * nchunk;
+      const long slots = CONV_SLOTS;
+      const long S = items_tot < slots ? items_tot : slots;
+      const long ndp = ntl / S;
+      const long rem = (ntl - ndp * S) * nchunk;
+      const double items = (double)(ndp * nchunk) + (double)((rem + S - 1) / S);
+      const bool paired = S > HPVG_NUM_CU;
+      const double per_item = (paired ? mfma_paired : mfma_paired * 3.0 / 6.5) + (paired ? 6.0 : 2.0) + stage_us;
+      const double tiles = (double)(ndp + (rem ? 1 : 0));
+      double parts = 0.0;
+      if (rem) {
+        parts = 1.0 + (double)rem / (double)S / (double)nchunk;
+        if (parts > 2.0) parts = 2.0;
+      }
+      cost = items * per_item + tiles * 0.4 * 4 + parts * 5.5 * 4 + 1e-4 * (double)ntl;
+    } else {
+      const long per_cu = (ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
+      const double tile_paired = nchunk * (mfma_paired + 6.0 + stage_us) + 1.6;
+      const double tile_alone = nchunk * (mfma_paired * 3.0 / 6.5 + 2.0 + stage_us) + 1.6;
+      cost = (double)(per_cu / 2) * tile_paired + (double)(per_cu & 1) * tile_alone + 1e-4 * (double)ntl;
+    }
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = Plan{0, Tw, RS, PL, L, L, nrange, ntw, hpvg_cdiv(L, 32), WINO_NBP, 2, gridy, hpvg_cdiv(plload, 256), lds};
+    }
+  }
+  return best;
+}
+
+// Which kernel a wide conv runs on (see wino_env_mode in conv_wino.inl).  Default threshold, measured per pyramid stage at
+// B = 2 (tools/perf_wino.py, profiles/r02_perf_wino.txt): the 3x3x3 convs gain at every stage (x1.14-1.18 at stages 0-1,
+// parity at 2, x1.08-1.32 from 3 up); the 3x3 convs are launch / fix-up bound below ~25 K output positions (x0.75-1.0) and
+// gain from there (x1.07-1.25 at stages 7-9).
+inline bool conv_use_wino(int B, int Cin, int Cout, int T, int H, int W, int KT, bool prologue) {
+  if (prologue || !conv_is_wino(Cin, Cout)) return false;
+  if (g_wino_mode < 0) {
+    g_wino_mode = wino_env_mode();
+    const char* e = getenv("HPVG_WINO_MIN");
+    if (e) g_wino_min_pos = atol(e);
+  }
+  if (g_wino_mode == 0) return false;
+  if (g_wino_mode == 2) return true;
+  const long min_pos = g_wino_min_pos >= 0 ? g_wino_min_pos : (KT == 3 ? 0L : 24000L);
+  return (long)B * T * H * W >= min_pos;
+}
+
 // The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).
 inline bool conv_is_narrow(int Cin, int Cout) { return Cout <= 4 && Cin > 4; }
 
-Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk) {
+Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool streamk, bool wino = false) {
   const bool narrow = conv_is_narrow(Cin, Cout);
   if (narrow) streamk = false;
   // open-addressing table (a ten-stage run touches ~150 distinct shapes; the search is up to ~100 us for wide 2-D images)
@@ -1124,13 +1227,13 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool strea
   constexpr int NSLOT = 2048;
   static thread_local Entry cache[NSLOT];
   static thread_local int filled = 0;
-  const Key k{B, Cin, Cout, T, H, W, KT, streamk ? 1 : 0};
+  const Key k{B, Cin, Cout, T, H, W, KT, (streamk ? 1 : 0) | (wino ? 2 : 0)};
   unsigned h = 2166136261u;
   for (int v : {B, Cin, Cout, T, H, W, KT, k.sk}) h = (h ^ (unsigned)v) * 16777619u;
   for (int probe = 0; probe < NSLOT; ++probe) {
     Entry& e = cache[(h + probe) & (NSLOT - 1)];
     if (!e.used) {
-      const Plan p = plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
+      const Plan p = wino ? plan_wino_search(B, Cin, Cout, T, H, W, KT, streamk) : plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
       if (filled < NSLOT / 2) {  // keep the table sparse; past that, shapes are simply planned again
         e.k = k; e.p = p; e.used = true;
         ++filled;
@@ -1140,7 +1243,7 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool strea
     const Key& c = e.k;
     if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT && c.sk == k.sk) return e.p;
   }
-  return plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
+  return wino ? plan_wino_search(B, Cin, Cout, T, H, W, KT, streamk) : plan_conv_search(B, Cin, Cout, T, H, W, KT, streamk, narrow);
 }
 
 // Launch of S workgroups.  The dynamic LDS request is padded to 56 KB so that a third workgroup never fits on a CU:
@@ -1193,6 +1296,34 @@ int dispatch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   }
 }
 
+template <int KT, int VAR>
+int launch_wino_var(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_wino_kernel<KT, WINO_NBP, VAR>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), p.lds < CONV_MIN_LDS ? CONV_MIN_LDS : p.lds, s, a);
+  int rc = hpvg_launch_status();
+  if (rc != HPVG_OK) return rc;
+  const int nsk = a.ntl - a.skbase;
+  if (nsk > 0) {
+    hipLaunchKernelGGL(conv_wino_fixup_kernel, dim3(nsk, WINO_NBP * 2), dim3(256), 0, s, a, S, WINO_NBP);
+    rc = hpvg_launch_status();
+  }
+  return rc;
+}
+
+template <int KT>
+int launch_wino(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+  if (a.mask || a.mask_bits) return launch_wino_var<KT, VAR_MASK>(a, p, S, s);
+  if (a.bits_out) return launch_wino_var<KT, VAR_BITS>(a, p, S, s);
+  return launch_wino_var<KT, VAR_PLAIN>(a, p, S, s);
+}
+
 template <int KT>
 int launch_conv_narrow(const ConvFwdArgs& a, const Plan& p, hipStream_t s) {
   const int ksteps = hpvg_cdiv(a.Cin * KT, 2);
@@ -1229,11 +1360,7 @@ extern "C" {
 // number of floats of the packed-weight buffer for a conv with Cin -> Cout (kernel view)
 size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) {
   if (conv_is_narrow(Cin, Cout)) return (size_t)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 64;  // wn[kstep][ntile][lane]
-  const int CC = conv_cc(Cin);
-  const int nchunk = hpvg_cdiv(Cin, CC);
-  const int mbtot = hpvg_cdiv(Cout, 32);
-  const size_t per_tap = (size_t)mbtot * 64 * (CC / 2);
-  return ((size_t)nchunk * KT * 9 + 2) * per_tap;  // +2 taps of zero tail padding (A prefetch runs one tap / one m-tile ahead)
+  return direct_pack_floats(Cin, Cout, KT) + (conv_is_wino(Cin, Cout) ? wino_pack_floats(Cin, Cout, KT) : 0);
 }
 
 // w: natural layout of the LAYER weight [Cout_layer][Cin_layer][KT][3][3].
@@ -1255,7 +1382,7 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
   const int mbtot = hpvg_cdiv(Cout_k, 32);
   const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
   hipLaunchKernelGGL(conv_pack_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
-                     Cin_k, Cout_k, KT * 9, CC, nchunk, mbtot, transpose_flip, total);
+                     Cin_k, Cout_k, KT * 9, CC, nchunk, mbtot, transpose_flip, (long)direct_pack_floats(Cin_k, Cout_k, KT), total);
   return hpvg_launch_status();
 }
 
@@ -1273,7 +1400,7 @@ int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* 
   const int mbtot = hpvg_cdiv(C, 32);
   const long total = (long)hpvg_conv_wpack_floats(C, C, KT);
   hipLaunchKernelGGL(conv_pack_batch_kernel, dim3(hpvg_cdiv(total, 256), n), dim3(256), 0, (hipStream_t)stream, a, C, KT * 9, CC,
-                     nchunk, mbtot, total);
+                     nchunk, mbtot, (long)direct_pack_floats(C, C, KT), total);
   return hpvg_launch_status();
 }
 
@@ -1322,12 +1449,18 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
   const int CC = conv_cc(Cin);
   const int nchunk = hpvg_cdiv(Cin, CC);
   bool streamk = !sk_off && ws != nullptr && !conv_is_narrow(Cin, Cout);
-  Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk);
+  bool wino = conv_use_wino(B, Cin, Cout, T, H, W, KT, in_scale != nullptr);
+  Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk, wino);
+  if (wino && p.L == 0) {  // no Winograd tile fits this shape: the direct kernel takes it
+    wino = false;
+    p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk, false);
+  }
   if (p.L == 0) return HPVG_ERR_UNSUPPORTED;
   int ntl = B * T * p.nrange * p.ntw * p.gridy;
   if (streamk && ws_bytes < conv_sk_ws_bytes(p, conv_sk_grid(ntl, nchunk, p))) {
     streamk = false;
-    p = plan_conv(B, Cin, Cout, T, H, W, KT, false);
+    p = plan_conv(B, Cin, Cout, T, H, W, KT, false, wino);
+    if (p.L == 0) return HPVG_ERR_UNSUPPORTED;
     ntl = B * T * p.nrange * p.ntw * p.gridy;
   }
   ConvFwdArgs a;
@@ -1356,6 +1489,10 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
   a.skbase = a.ndp * S;
   a.skpart = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
+  if (wino) {
+    a.wp = wp + direct_pack_floats(Cin, Cout, KT);   // the U fragments follow the direct pack
+    return KT == 3 ? launch_wino<3>(a, p, S, s) : launch_wino<1>(a, p, S, s);
+  }
   if (CC == 8) return KT == 3 ? dispatch_conv<8, 3>(a, p, S, s) : dispatch_conv<8, 1>(a, p, S, s);
   return KT == 3 ? dispatch_conv<4, 3>(a, p, S, s) : dispatch_conv<4, 1>(a, p, S, s);
 }
@@ -1364,9 +1501,16 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;
   if (conv_is_narrow(Cin, Cout)) return 0;
-  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
-  if (p.L == 0) return 0;
-  return conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nrange * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin)), p));
+  // the larger of the two kernels' needs: a launch with a BatchNorm prologue runs the direct kernel on a Winograd shape
+  size_t need = 0;
+  for (int wino = 0; wino < 2; ++wino) {
+    if (wino && !conv_use_wino(B, Cin, Cout, T, H, W, KT, false)) break;
+    const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true, wino != 0);
+    if (p.L == 0) continue;
+    const size_t n = conv_sk_ws_bytes(p, conv_sk_grid(B * T * p.nrange * p.ntw * p.gridy, hpvg_cdiv(Cin, conv_cc(Cin)), p));
+    if (n > need) need = n;
+  }
+  return need;
 }
 
 // Debug/introspection: the tile plan of the stream-K launch (for tests and DESIGN.md tables).
@@ -1377,6 +1521,30 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
   const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true);
   out[0] = p.L; out[1] = p.Tw; out[2] = p.nrange; out[3] = p.ntw; out[4] = p.nblocks; out[5] = p.NB; out[6] = p.MB;
   out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nrange * p.ntw;
+  return HPVG_OK;
+}
+
+// Run-time switch of the Winograd path (tests and A/B tools; see wino_env_mode): mode 0 = direct kernel only, 1 = from
+// `min_positions` output positions up, 2 = every eligible launch; a negative argument leaves that setting alone.  Returns
+// the mode in force, or HPVG_ERR_UNSUPPORTED when the library was started with HPVG_WINO=0 (packs carry no U fragments).
+int hpvg_conv_wino_config(int mode, long min_positions) {
+  if (wino_env_mode() == 0) return HPVG_ERR_UNSUPPORTED;
+  (void)conv_use_wino(1, 8, 64, 1, 1, 1, 3, false);   // settle the defaults
+  if (mode >= 0) g_wino_mode = mode > 2 ? 2 : mode;
+  if (min_positions >= 0) g_wino_min_pos = min_positions;
+  return g_wino_mode;
+}
+
+// Debug/introspection: the tile plan conv_wino_kernel would run this shape with (whether or not the launch picks it):
+// out[0..9] = L, Tw, nrange, ntw, RS, NBP, m-tiles per workgroup, gridy, lds_bytes, ntiles; HPVG_ERR_UNSUPPORTED when the
+// layer is not eligible (Cin < 8, Cout <= 32) or no tile fits.
+int hpvg_conv_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3) || B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
+  if (!conv_is_wino(Cin, Cout)) return HPVG_ERR_UNSUPPORTED;
+  const Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, true, true);
+  if (p.L == 0) return HPVG_ERR_UNSUPPORTED;
+  out[0] = p.L; out[1] = p.Tw; out[2] = p.nrange; out[3] = p.ntw; out[4] = p.RS; out[5] = p.NB; out[6] = p.MB;
+  out[7] = p.gridy; out[8] = (int)p.lds; out[9] = B * T * p.nrange * p.ntw * p.gridy;
   return HPVG_OK;
 }
 

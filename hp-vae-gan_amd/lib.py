@@ -36,6 +36,8 @@ _SIGS = {
     "hpvg_conv_fwd_bits_f32": [P, P, P, P, I, P, P, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_fwd_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_narrow_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_wino_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_wino_config": [I, L],
     "hpvg_conv_bwd_weight_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],

@@ -60,6 +60,16 @@ int hpvg_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, f
                            unsigned* bits_out, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT,
                            void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
+/* Wide layers (kernel view Cin >= 8, Cout > 32) have a second kernel behind the same entry points: Winograd F(2,3) along W
+ * (four products per output pair and (dt, dh) instead of six, summed over the channels before the output transform: 2/3 of
+ * the matrix-core work; fp32, ~1e-6 of the output scale away from the direct kernel).  The weight pack carries both forms;
+ * which kernel a launch runs is decided per shape.  hpvg_conv_wino_config: mode 0 = direct kernel only, 1 = Winograd from
+ * `min_positions` output positions (B*T*H*W) up, 2 = every eligible launch; a negative argument leaves that setting as it
+ * is; returns the mode in force (HPVG_ERR_UNSUPPORTED when the process was started with HPVG_WINO=0).  Host only. */
+int hpvg_conv_wino_config(int mode, long min_positions);
+/* host only: the Winograd kernel's tile plan: out[0..9] = L, Tw, nrange, ntw, RS, pair blocks per wave, m-tiles per
+ * workgroup, gridy, lds_bytes, ntiles */
+int hpvg_conv_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10);
 /* host only: tile plan of the narrow-output kernel (Cout <= 4): out[0..6] = RS, Th, nth, nb, npos, G, pitch, then nb triples
  * (window start, first output column, output columns); out needs 7 + 3*16 ints */
 int hpvg_conv_narrow_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out55);

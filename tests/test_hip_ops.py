@@ -84,6 +84,86 @@ def test_conv_stream_k_schedules_and_plain_launch(ops, B, Cin, Cout, sp):
     assert_close(y_pl, y_sk, 1e-5, "conv.plain-vs-streamk")
 
 
+@pytest.fixture
+def wino_mode():
+    """Switch the Winograd path (hpvg_conv_wino_config) for one test; restored afterwards."""
+    from hp_vae_gan_amd import lib as hplib
+    lib = hplib.load()
+    prev = lib.hpvg_conv_wino_config(-1, -1)
+
+    def set_mode(m):
+        assert lib.hpvg_conv_wino_config(m, -1) == m
+    yield set_mode
+    lib.hpvg_conv_wino_config(prev, -1)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,sp", [
+    (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 16, 40, (3, 4, 7)),
+    (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (2, 64, 64, (5, 45, 81)), (1, 64, 64, (1, 1, 1)),
+    (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),
+])
+def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
+    """conv_wino_kernel (F(2,3) along W; every eligible launch forced onto it) against the oracle and against the direct
+    kernel on the same inputs: forward, backward-data (flipped pack), LeakyReLU epilogue + 1-bit mask output, masked
+    epilogues (1-bit and fp32 masks), stream-K and one-workgroup-per-tile launches; odd and tiny widths, ragged channel
+    counts, two output-channel groups, cut tiles finished by conv_wino_fixup_kernel."""
+    import ctypes
+    from hp_vae_gan_amd import lib as hplib
+    nd = len(sp)
+    x = _rand(B, Cin, *sp, seed=21)
+    w = _rand(Cout, Cin, *([3] * nd), seed=22, scale=0.05)
+    b = _rand(Cout, seed=23)
+    gy = _rand(B, Cout, *sp, seed=24)
+    want = O.conv(x, w, b)
+    xr = x.clone().requires_grad_(True)
+    (want_dx,) = torch.autograd.grad(O.conv(xr, w, None), xr, gy)
+    act = O.leaky_relu(want)
+    xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    res = {}
+    for mode in (2, 0):
+        wino_mode(mode)
+        y = ops.conv_fwd_raw(xd, wd, bd)
+        dx = ops.conv_fwd_raw(gyd, wd, None, flip=True)
+        ya, bits = ops.conv_fwd_raw(xd, wd, bd, out_lrelu=True, want_bits=True)
+        # the layer below's leaky_relu_backward in this layer's backward-data epilogue: mask = sign of x (any tensor of dx's shape)
+        xbits_src, xbits = ops.conv_fwd_raw(gyd, wd, None, flip=True, out_lrelu=True, want_bits=True) if Cin > 4 else (None, None)
+        dxm_bits = ops.conv_fwd_raw(gyd, wd, None, flip=True, mask_bits=xbits)
+        dxm_f32 = ops.conv_fwd_raw(gyd, wd, None, flip=True, out_mask=xd)
+        Bq, C, T, H, W = ops.geom(xd)
+        KT = 3 if nd == 3 else 1
+        wp = ops.pack_weight(wd, False)
+        y_pl = torch.full_like(y, float("nan"))
+        hplib.call("hpvg_conv_fwd_f32", hplib.ptr(xd), hplib.ptr(wp), hplib.ptr(bd), None, None, 0, hplib.ptr(y_pl), 0, None, None,
+                   ctypes.c_size_t(0), Bq, Cin, Cout, T, H, W, KT, hplib.stream())
+        res[mode] = dict(y=y, dx=dx, ya=ya, bits=bits, dxm_bits=dxm_bits, dxm_f32=dxm_f32, y_pl=y_pl, xbits_src=xbits_src)
+    for mode, r in res.items():
+        tag = "wino." if mode == 2 else "direct."
+        assert_close(r["y"], want, RTOL, tag + "y")
+        assert_close(r["y_pl"], want, RTOL, tag + "y.plain-launch")
+        assert_close(r["dx"], want_dx, RTOL, tag + "dx")
+        assert_close(r["ya"], act, RTOL, tag + "lrelu")
+        assert_close(r["dxm_f32"], want_dx * torch.where(x > 0, 1.0, 0.2), RTOL, tag + "dx.mask_f32")
+        # the 1-bit mask this launch read is the sign pattern of its own producer launch
+        m = torch.where(r["xbits_src"] > 0, 1.0, 0.2)
+        assert_close(r["dxm_bits"], r["dx"] * m, 1e-6, tag + "dx.mask_bits")
+    # Winograd against the direct kernel: rounding only (measured ~1e-6 of the output scale)
+    for k in ("y", "dx", "ya", "y_pl", "dxm_f32"):
+        assert_close(res[2][k], res[0][k], 2e-5, "wino-vs-direct." + k)
+    # the sign bits agree wherever the activation is not within rounding of zero
+    far = (want.abs() > 1e-4 * float(want.abs().max())).to(DEV)
+    sa, sb = res[2]["ya"] > 0, res[0]["ya"] > 0
+    assert bool(((sa == sb) | ~far).all())
+    cw = hplib.call("hpvg_conv_mask_words", B, Cout, *((ops.geom(xd))[2:]))
+    assert res[2]["bits"].numel() == cw
+    # bits written by the Winograd epilogue decode to the sign of its own output
+    mt = (Cout + 31) // 32
+    bw = res[2]["bits"].view(B, -1, mt).cpu()
+    yw = res[2]["ya"].reshape(B, Cout, -1).cpu()
+    for c in (0, Cout // 2, Cout - 1):
+        got = (bw[:, :, c // 32] >> (c % 32)) & 1
+        assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
+
+
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
 def test_conv_lrelu_epilogue_and_affine_prologue(ops, B, Cin, Cout, sp):
     nd = len(sp)

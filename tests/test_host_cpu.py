@@ -26,7 +26,9 @@ def test_library_loads_and_exports_header_symbols():
 
 
 def test_size_queries_and_plans_run_without_gpu():
-    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 3) == (8 * 27 + 2) * 2 * 64 * 4
+    # wide layers carry the Winograd U fragments (36 tap-points per chunk + 4 of tail padding) behind the direct pack
+    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 3) == (8 * 27 + 2) * 2 * 64 * 4 + (8 * 36 + 4) * 2 * 64 * 4
+    assert hplib.call("hpvg_conv_wpack_floats", 64, 32, 3) == (8 * 27 + 2) * 1 * 64 * 4     # Cout <= 32: direct kernel only
     assert hplib.call("hpvg_conv_wpack_floats", 3, 64, 3) == (1 * 27 + 2) * 2 * 64 * 2
     out = (ctypes.c_int * 10)()
     for (B, Ci, Co, T, H, W, KT) in [(2, 64, 64, 13, 144, 256, 3), (2, 64, 64, 4, 18, 33, 3), (2, 3, 64, 1, 192, 256, 1), (2, 64, 3, 7, 91, 162, 3)]:
@@ -41,6 +43,31 @@ def test_size_queries_and_plans_run_without_gpu():
         assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT) > 0
     with pytest.raises(RuntimeError, match="HPVG_ERR_ARG"):  # bad KT -> error code, not a crash
         hplib.call("hpvg_conv_fwd_plan", 1, 1, 1, 1, 1, 1, 2, out)
+
+
+def test_winograd_conv_plan_geometry():
+    """The tile plan of conv_wino_kernel over every width: even band width and row stride (an output pair never straddles a
+    row or a band), even tile length within the accumulator blocks, every output position covered, every LDS read of a
+    lane inside the tile buffer, the staged plane within the 4 x 256 staging slots."""
+    lib = hplib.load()
+    out = (ctypes.c_int * 10)()
+    assert lib.hpvg_conv_wino_plan(2, 3, 64, 5, 9, 16, 3, out) != 0     # Cin < 8: direct kernel
+    assert lib.hpvg_conv_wino_plan(2, 64, 32, 5, 9, 16, 3, out) != 0    # one m-tile: direct kernel
+    for KT, T in ((3, 5), (1, 1)):
+        for H in (1, 2, 9, 45, 144):
+            for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 230, 255, 256, 300]:
+                for Cout in (64, 70, 128):
+                    assert lib.hpvg_conv_wino_plan(2, 64, Cout, T, H, W, KT, out) == 0, (KT, H, W)
+                    L, Tw, nrange, ntw, RS, NBP, MBW, gridy, lds, ntiles = list(out)
+                    assert Tw % 2 == 0 and RS == Tw + 2 and L % 2 == 0 and 2 <= L <= NBP * 128
+                    assert ntw * Tw >= W and (ntw - 1) * Tw < W
+                    assert nrange * L >= (H - 1) * RS + Tw                 # every output position of a band plane
+                    assert gridy * MBW * 32 >= Cout and ntiles == 2 * T * nrange * ntw * gridy
+                    PL = NBP * 128 + 2 * RS + 2
+                    assert lds == 8 * KT * PL * 4 and lds <= 80 * 1024
+                    assert L + 2 * RS + 2 <= 1024                          # staged positions per plane
+                    # furthest read of a lane: pair NBP*64 - 1, row tap 2, inputs d2 d3
+                    assert 2 * (NBP * 64 - 1) + 2 * RS + 3 < PL
 
 
 def test_tables_match_reference():
