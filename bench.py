@@ -303,7 +303,7 @@ def main():
             dist.init_process_group(backend)
 
     import hp_vae_gan_amd  # noqa: F401  (fails loudly if libhpvg.so is missing)
-    from hp_vae_gan_amd import ops
+    from hp_vae_gan_amd import ops, lib as hplib
 
     if world > 1:
         from hp_vae_gan_amd import multigpu
@@ -406,11 +406,21 @@ def main():
             flops = 2.0 * B * 64 * 64 * (9 * KT) * T * H * W
             achieved = flops / (ms * 1e-3) / 1e12
             traffic, traffic_src = measured_traffic(key)
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)" % ("3x3x3" if KT == 3 else "3x3"),
+            # which kernel ran these launches (conv_mfma.hip conv_use_wino: Winograd F(2,3) along W unless switched off or,
+            # for the 3x3 convs, below 24 K output positions): `achieved` / `frac` price the ALGORITHMIC flops of the conv
+            #  as the contract asks; the Winograd kernel EXECUTES 2/3 of them on the matrix cores, reported beside
+            mode = hplib.load().hpvg_conv_wino_config(-1, -1)
+            wmin = os.environ.get("HPVG_WINO_MIN")
+            wino = mode == 2 or (mode == 1 and B * T * H * W >= (int(wmin) if wmin else (0 if KT == 3 else 24000)))
+            kname = ("conv_wino_kernel + conv_wino_fixup_kernel (64->64 %s fwd, Winograd F(2,3) along W, stream-K, fp32 v_mfma_f32_32x32x2_f32)"
+                     if wino else "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)") % ("3x3x3" if KT == 3 else "3x3")
+            executed = flops * (2.0 / 3.0 if wino else 1.0)
+            roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 9 * KT, "shape": list(key),
-                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops, "rank": owner}
+                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops, "rank": owner,
+                    "executed_flops_per_launch": executed, "matrix_pipe_frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1 and CONFIG == "video":
             cs = [s for s in parse(args.cpu_stages) if s in stages]

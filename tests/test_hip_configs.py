@@ -37,7 +37,10 @@ def test_eight_scale_configs_run_on_one_gpu(config):
     assert its[7] < its[3] < its[0], "iterations get slower as the pyramid grows"
     roof = line["roofline"]
     # the dominant kernel ran at the finest stage: 13 frames at 256 wide (the baseline's valid convs run on padded volumes)
-    assert roof["shape"][0] in (2, 4) and roof["shape"][2] >= 13 and roof["shape"][4] >= 256 and 0.2 < roof["frac"] < 1.0
+    # (`frac` prices the conv's ALGORITHMIC flops: the Winograd kernel executes 2/3 of them, so it may pass 1; what the
+    # matrix cores actually ran stays under their peak)
+    assert roof["shape"][0] in (2, 4) and roof["shape"][2] >= 13 and roof["shape"][4] >= 256 and 0.2 < roof["frac"] < 1.5
+    assert 0.2 < roof["matrix_pipe_frac"] < 1.0 and roof["executed_flops_per_launch"] <= roof["flops_per_launch"]
 
 
 @pytest.mark.parametrize("config", ["video8", "baseline"])
