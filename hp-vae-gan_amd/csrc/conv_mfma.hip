@@ -1165,7 +1165,9 @@ Plan plan_wino_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
     const size_t lds = (size_t)WINO_CC * KT * PL * sizeof(float);
     if (lds > 80 * 1024) continue;
     const long ntl = (long)B * T * nrange * ntw * gridy;
-    const double stage_us = 0.002 * plload;
+    // (staging weighs half of what it does for the direct kernel: measured landscape, profiles/r02_ab_wino_plan.txt - wide
+    // bands with few junk columns win at stages 7-9 although they stage three rows per row of outputs)
+    const double stage_us = 0.001 * plload;
     const double mfma_paired = 6.5 * (2.0 * WINO_NBP) * (2.0 / 3.0);  // 64 ch x NBP*64 pairs = 2*NBP direct 32x32 block pairs, at 36/54 of their k-steps
     double cost;
     if (streamk) {

@@ -249,6 +249,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+#include "conv_wgrad_wino.inl"
+
 // ------------------------------------------------------------------------------------------
 // Backward-weight of the 3x3x3 conv, second generation: ONE workgroup owns all 27 taps of a 64(o) x 32(c) block.
 // conv_wgrad_kernel gives each time tap its own workgroup, so a dY tile is staged by three workgroups and an X plane by
@@ -1112,6 +1114,85 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   return plan_wgrad_search(B, Cin, Cout, T, H, W, KT);
 }
 
+// Tile plan of conv_wgradw_kernel (Winograd along W): the tile family of conv_wgrad_kernel with an EVEN band width and row
+// stride, channel strides of 2 (mod 4) and the Winograd K loop's cost (12 MFMAs per 4 positions instead of 18).
+WPlan plan_wgradw_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  WPlan best{};
+  double best_cost = 1e300;
+  const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
+  int prev_tw = 0;
+  for (int ntw = W; ntw >= 1; --ntw) {
+    int Tw = hpvg_cdiv(W, ntw);
+    Tw += Tw & 1;
+    if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;
+    prev_tw = Tw;
+    const int RS = Tw + 2;
+    for (int Th = 1; Th <= H; ++Th) {
+      const int nth = hpvg_cdiv(H, Th);
+      if (Th != hpvg_cdiv(H, nth)) continue;
+      const int QK = (Th * RS + 3) & ~3;                 // K positions, padded to the 4-position (2-pair) loop step
+      const int DS = QK + 2;                             // dY row stride: >= QK, 2 (mod 4)
+      int XS = QK + 2 * RS + 2;                          // X row: reads reach QK + 2*RS + 1
+      if (XS < (Th + 2) * RS) XS = (Th + 2) * RS;
+      while ((XS & 3) != 2) ++XS;
+      if (DS > 512 || XS > 512) break;
+      const size_t lds = (size_t)2 * 64 * (DS + XS) * sizeof(float);  // two tile buffers
+      if (lds > 156 * 1024) break;
+      const long ntiles = (long)B * T * nth * ntw;
+      const double work = (double)ntiles * (QK * 0.25 * 12.0 + 40.0);
+      if (work < best_cost) {
+        best_cost = work;
+        best = WPlan{Th, Tw, RS, DS, XS, QK, nth, ntw, 0, nob, ncb, lds};
+      }
+    }
+  }
+  if (best.Th) {
+    const long ntiles = (long)B * T * best.nth * best.ntw;
+    long cap = (long)HPVG_NUM_CU / ((long)KT * nob * ncb);  // one persistent workgroup per CU
+    if (cap < 1) cap = 1;
+    best.S = (int)(ntiles < cap ? ntiles : cap);
+    best.S0 = best.S;
+    if (KT == 3 && T >= 2 && best.S >= 2) {   // tiles-with-work per workgroup equal over the three time taps (plan_wgrad_search)
+      const long Stot = 3L * best.S;
+      long S1 = (Stot * T + (3L * T - 2) / 2) / (3L * T - 2);
+      if (S1 > ntiles) S1 = ntiles;
+      long S0 = (Stot - S1) / 2;
+      if (S0 < 1) S0 = 1;
+      if (S0 > S1) S0 = S1;
+      best.S = (int)S1;
+      best.S0 = (int)S0;
+    }
+  }
+  return best;
+}
+WPlan plan_wgradw(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  struct Key { int B, Cin, Cout, T, H, W, KT; };
+  struct Entry { Key k; WPlan p; };
+  constexpr int NE = 256;
+  static thread_local Entry cache[NE];
+  static thread_local int filled = 0;
+  for (int i = 0; i < filled; ++i) {
+    const Key& c = cache[i].k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return cache[i].p;
+  }
+  const WPlan p = plan_wgradw_search(B, Cin, Cout, T, H, W, KT);
+  if (filled < NE) cache[filled++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
+  return p;
+}
+inline size_t wgradw_ws_bytes(const WPlan& p, int KT) { return 256 + (size_t)p.S * KT * p.nob * p.ncb * 12 * 4096 * sizeof(float); }
+// HPVG_WGRAD_WINO (read once; hpvg_conv_bwd_weight_wino_config changes it at run time): 0 = never the Winograd weight
+// gradient, 2 = every wide layer, 1 / unset = by size (see wgradw_wanted)
+int g_wgradw_mode = -1;
+inline bool wgradw_wanted(const WPlan& p, int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (g_wgradw_mode < 0) {
+    const char* e = getenv("HPVG_WGRAD_WINO");
+    g_wgradw_mode = e ? atoi(e) : 1;
+  }
+  if (g_wgradw_mode == 0 || p.Th == 0 || Cin <= 4 || Cout <= 4) return false;
+  if (g_wgradw_mode == 2) return true;
+  return true;
+}
+
 // tile plan of conv_wgrad3_kernel: the same tile family as conv_wgrad_kernel under its own LDS budget (two dY tiles, four
 // 32-channel X planes, one row of zeros); S persistent workgroups per (64 output, 32 input channel) block pair
 struct W3Plan { int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb; size_t lds; long ntiles; bool ok; };
@@ -1225,6 +1306,8 @@ size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int
     const W3Plan q = plan_wgrad3(B, Cin, Cout, T, H, W);
     if (wgrad3_wanted(q) && wgrad3_ws_bytes(q) > need) need = wgrad3_ws_bytes(q);
   }
+  const WPlan pw = plan_wgradw(B, Cin, Cout, T, H, W, KT);
+  if (g_wgradw_mode != 0 && pw.Th != 0 && wgradw_ws_bytes(pw, KT) > need) need = wgradw_ws_bytes(pw, KT);  // (any run-time mode)
   return need;
 }
 
@@ -1315,6 +1398,49 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
     return hpvg_launch_status();
   }
   if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
+  {
+    const WPlan pw = plan_wgradw(B, Cin, Cout, T, H, W, KT);
+    if (wgradw_wanted(pw, B, Cin, Cout, T, H, W, KT)) {
+      // ---- Winograd along W (conv_wgradw_kernel): 12 tap-point accumulators per time tap, transformed by the reduce kernel
+      if (ws_bytes < wgradw_ws_bytes(pw, KT)) return HPVG_ERR_WORKSPACE;
+      WgradArgs a;
+      a.dy = dy; a.x = x; a.in_scale = nullptr; a.in_shift = nullptr;
+      a.part = (float*)((char*)ws + 256);
+      a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
+      a.Th = pw.Th; a.Tw = pw.Tw; a.RS = pw.RS; a.DS = pw.DS; a.XS = pw.XS; a.QK = pw.QK; a.nth = pw.nth; a.ntw = pw.ntw;
+      a.S = pw.S; a.S0 = pw.S0; a.ncb = pw.ncb; a.nob = pw.nob; a.in_lrelu = 0;
+      hipStream_t s = (hipStream_t)stream;
+      const dim3 grid((KT == 3 ? 2 * pw.S0 + pw.S : pw.S) * pw.nob * pw.ncb);
+      const int njd = pw.DS > 256 ? 2 : 1, njx = pw.XS > 256 ? 2 : 1;
+#define HPVG_WW_LAUNCH(K, D, X)                                                                                        \
+  {                                                                                                                    \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X>),                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
+        (void)hipGetLastError();                                                                                       \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X>), grid, dim3(256), pw.lds, s, a);                                  \
+  }
+      if (KT == 3) {
+        if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(3, 1, 1)
+        else if (njd == 1) HPVG_WW_LAUNCH(3, 1, 2)
+        else HPVG_WW_LAUNCH(3, 2, 2)
+      } else {
+        if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(1, 1, 1)
+        else if (njd == 1) HPVG_WW_LAUNCH(1, 1, 2)
+        else HPVG_WW_LAUNCH(1, 2, 2)
+      }
+#undef HPVG_WW_LAUNCH
+      int stw = hpvg_launch_status();
+      if (stw != HPVG_OK) return stw;
+      const long totw = (long)KT * pw.nob * pw.ncb * 3 * 4096;
+      hipLaunchKernelGGL(conv_wgradw_reduce_kernel, dim3(hpvg_cdiv(totw, 128)), dim3(128, 8), 0, s, (const float*)a.part, dw, pw.S, pw.S0,
+                         KT, pw.nob, pw.ncb, Cout, Cin, accumulate);
+      return hpvg_launch_status();
+    }
+  }
   if (KT == 3) {
     const W3Plan q = plan_wgrad3(B, Cin, Cout, T, H, W);
     if (wgrad3_wanted(q)) {
@@ -1411,6 +1537,24 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
   hipLaunchKernelGGL(channel_sum_finish_kernel, dim3(hpvg_cdiv(C, 64)), dim3(64), 0, s, (const double*)ws, ns, C, out,
                      accumulate);
   return hpvg_launch_status();
+}
+
+// Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer; a
+// negative mode only queries.  Returns the mode in force.
+int hpvg_conv_bwd_weight_wino_config(int mode) {
+  (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the default
+  if (mode >= 0) g_wgradw_mode = mode > 2 ? 2 : mode;
+  return g_wgradw_mode;
+}
+
+// host only: the tile plan of the Winograd weight-gradient kernel: out[0..9] as hpvg_conv_bwd_weight_plan
+int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3) || B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
+  const WPlan p = plan_wgradw(B, Cin, Cout, T, H, W, KT);
+  if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.QK; out[5] = p.S; out[6] = p.DS; out[7] = p.XS;
+  out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
+  return HPVG_OK;
 }
 
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {

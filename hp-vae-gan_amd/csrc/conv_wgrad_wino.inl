@@ -1,0 +1,265 @@
+// Weight gradient of the wide 3x3 / 3x3x3 convs with the TRANSPOSE of the forward Winograd F(2,3) along W (conv_wino.inl) -
+// included by conv_wgrad.hip inside its anonymous namespace (shares WgradArgs, the zero word and the tile family with
+// conv_wgrad_kernel, whose structure it keeps: one time tap and one 64 x 64 (o, c) block per persistent workgroup, one
+// 32 x 32 sub-block per wave, two LDS tile buffers filled by LDS-DMA in the shadow of the MFMAs, one partial slab at the end).
+//
+// Same reference call sites as conv_wgrad_kernel (the weight half of aten::convolution_backward, train_video.py:182,200,
+// train_image.py:193,215, and the gradient penalty's double backward, modules/utils.py:14-18).  For one pair of output
+// columns (w, w+1) of a row, gradients y0 y1 and inputs d0..d3 (columns w-1..w+2) of row h+dh-1, the three dw taps
+//       g0 += y0 d0 + y1 d1,  g1 += y0 d1 + y1 d2,  g2 += y0 d2 + y1 d3                              (6 multiplies)
+// are regrouped into four products  m_j = Y_j * V_j  with
+//       Y = (y0, y0 + y1, y0 - y1, -y1)              V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+//       g0 = m0 + (m1 + m2)/2,  g1 = (m1 - m2)/2,  g2 = (m1 + m2)/2 + m3                             (4 multiplies)
+// and every m_j is summed over all pairs, planes and samples BEFORE the (linear) output transform, which the reduce kernel
+// applies once per weight.  GEMM per (dt, dh, j): M = o, N = c, K = output PAIRS - 12 accumulator tiles per wave instead
+// of 9 on half the k-steps: 2/3 of the matrix-core work.  fp32 throughout.
+// Layout rules on top of conv_wgrad_kernel's: the row stride RS = Tw + 2 is EVEN (a pair never straddles a row) and the
+// channel strides DS, XS are 2 (mod 4): a half-wave's 32 channel rows read 8-byte pairs from 32 different bank pairs.
+
+typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int KT, int NJD, int NJX>
+__global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int oblk = wave >> 1, cblk = wave & 1;
+  // workgroup ids as in conv_wgrad_kernel: time tap fastest, then the persistent slot; the outer taps get S0 <= S slots
+  const int nz = a.nob * a.ncb;
+  const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const int Stot = KT == 3 ? 2 * a.S0 + a.S : a.S;
+  const int idx = L % Stot;
+  const int z = L / Stot;
+  int dt = 0, slot = idx, nslot = a.S;
+  if (KT == 3) {
+    if (idx < 3 * a.S0) {
+      dt = idx % 3;
+      slot = idx / 3;
+      nslot = dt == 1 ? a.S : a.S0;
+    } else {
+      dt = 1;
+      slot = a.S0 + idx - 3 * a.S0;
+    }
+  }
+  const int ob = z / a.ncb, cb = z % a.ncb;
+  const int RS = a.RS, DS = a.DS, XS = a.XS;
+  const int BUF = 64 * (DS + XS);
+  const long HW = (long)a.H * a.W;
+  const long cstride = (long)a.T * HW;
+  const bool active = (ob * 64 + oblk * 32 < a.Cout) && (cb * 64 + cblk * 32 < a.Cin);
+  int no = a.Cout - ob * 64; if (no > 64) no = 64;   // channels present in this 64-block
+  int nc = a.Cin - cb * 64;  if (nc > 64) nc = 64;
+  const int pt = (KT == 3 ? 1 : 0);
+  const int ntiles = a.B * a.T * a.nth * a.ntw;
+
+  f32x16 acc[12];   // [dh][j]
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+  // zero both buffers once: rows of absent channels are never written afterwards
+  for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* dptr[NJD];
+  const char* xptr[NJX];
+  unsigned dstr[NJD], xstr[NJX];
+  bool dln[NJD], xln[NJX];
+#pragma unroll
+  for (int j = 0; j < NJD; ++j) dln[j] = j * 256 + tid < DS;
+#pragma unroll
+  for (int j = 0; j < NJX; ++j) xln[j] = j * 256 + tid < XS;
+  const unsigned cbytes = (unsigned)(cstride * 4);
+  auto setup = [&](int tile) {
+    const int t = tile % a.T;  // time-major tile order
+    int r = tile / a.T;
+    const int tw_i = r % a.ntw;
+    r /= a.ntw;
+    const int th_i = r % a.nth;
+    const int b = r / a.nth;
+    const int tt = t + dt - pt;
+    const bool tok = tt >= 0 && tt < a.T;
+    const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
+    const float* dyb = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
+    const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + (tok ? tt : 0)) * HW;
+#pragma unroll
+    for (int j = 0; j < NJD; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
+      dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
+      dstr[j] = ok ? cbytes : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NJX; ++j) {
+      const int p = j * 256 + tid;
+      const int hh = p / RS, ww = p - hh * RS;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
+      xstr[j] = ok ? cbytes : 0u;
+    }
+  };
+  float* dma_d = lds;
+  float* dma_x = lds;
+  auto dma_begin = [&](float* buf) {
+    dma_d = buf + wave * 64;
+    dma_x = buf + 64 * DS + wave * 64;
+  };
+  auto dma_channel = [&](int c) {
+    if (c < no) {
+#pragma unroll
+      for (int j = 0; j < NJD; ++j) {
+        if (dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * 256), 4, 0, 0);
+        dptr[j] += dstr[j];
+      }
+    }
+    if (c < nc) {
+#pragma unroll
+      for (int j = 0; j < NJX; ++j) {
+        if (xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * 256), 4, 0, 0);
+        xptr[j] += xstr[j];
+      }
+    }
+    dma_d += DS;
+    dma_x += XS;
+  };
+
+  int tile = slot;
+  __syncthreads();  // zero fill done
+  if (tile < ntiles) {
+    setup(tile);
+    dma_begin(lds);
+    for (int c = 0; c < 64; ++c) dma_channel(c);
+  }
+  __syncthreads();  // (waits for the DMA: pending LDS-DMA counts on vmcnt)
+
+  const int nsteps = a.QK >> 2;  // K-loop iterations: 4 positions = 2 pairs = ONE MFMA k-step per tap-point
+  int cur = 0;
+  for (; tile < ntiles; tile += nslot) {
+    const int next = tile + nslot;
+    const bool have_next = next < ntiles;
+    float* bufc = lds + cur * BUF;
+    int cnext = 64;                // next channel to stage (64 = nothing left)
+    if (have_next) {
+      setup(next);
+      dma_begin(lds + (cur ^ 1) * BUF);
+      cnext = 0;
+    }
+    const int tt_cur = tile % a.T + dt - pt;
+    if (active && tt_cur >= 0 && tt_cur < a.T) {
+      // this lane's pair of step st: positions 4 st + 2 half, + 1
+      const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
+      const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half;
+      // two register sets: the LDS reads of step st+1 are issued before the MFMAs of step st
+      wf32x2a pa, pb0[3], pb1[3], qa, qb0[3], qb1[3];
+#define WW_LOAD(A, B0, B1, ST)                                                           \
+  {                                                                                      \
+    const int q0_ = (ST) * 4;                                                            \
+    A = *reinterpret_cast<const wf32x2a*>(dl + q0_);                                     \
+    _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                   \
+      B0[dh] = *reinterpret_cast<const wf32x2a*>(xl + q0_ + dh * RS);                    \
+      B1[dh] = *reinterpret_cast<const wf32x2a*>(xl + q0_ + dh * RS + 2);                \
+    }                                                                                    \
+  }
+// 12 MFMAs with three channels of DMA staging slotted in between (the rate per position of conv_wgrad_kernel)
+#define WW_MMA(A, B0, B1)                                                                                          \
+  {                                                                                                                \
+    const float y0_ = A[0], y1_ = A[1];                                                                            \
+    const float ys_ = y0_ + y1_, yd_ = y0_ - y1_, yn_ = -y1_;                                                      \
+    _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                                             \
+      const float d0_ = B0[dh][0], d1_ = B0[dh][1], d2_ = B1[dh][0], d3_ = B1[dh][1];                              \
+      acc[dh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0_, d0_ - d2_, acc[dh * 4 + 0], 0, 0, 0);            \
+      acc[dh * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ys_, d1_ + d2_, acc[dh * 4 + 1], 0, 0, 0);            \
+      acc[dh * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(yd_, d2_ - d1_, acc[dh * 4 + 2], 0, 0, 0);            \
+      acc[dh * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yn_, d1_ - d3_, acc[dh * 4 + 3], 0, 0, 0);            \
+      if (cnext < 64) { dma_channel(cnext); ++cnext; }                                                             \
+    }                                                                                                              \
+  }
+      int st = 0;
+      if (st < nsteps) WW_LOAD(pa, pb0, pb1, st);
+      for (; st + 1 < nsteps; st += 2) {
+        WW_LOAD(qa, qb0, qb1, st + 1);
+        WW_MMA(pa, pb0, pb1);
+        if (st + 2 < nsteps) WW_LOAD(pa, pb0, pb1, st + 2);
+        WW_MMA(qa, qb0, qb1);
+      }
+      if (st < nsteps) WW_MMA(pa, pb0, pb1);
+#undef WW_LOAD
+#undef WW_MMA
+    }
+    while (cnext < 64) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
+    __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
+    cur ^= 1;
+  }
+
+  // ---- partial slab: part[s][dt][z][dh*4 + j][o64][c64]
+  float* pp = a.part + ((((long)slot * KT + dt) * nz + z) * 12) * 4096;
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = oblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      pp[(long)k * 4096 + row * 64 + cblk * 32 + l31] = active ? acc[k][e] : 0.f;
+    }
+}
+
+// dW[o][c][dt][dh][0..2] = G^T sum_s part[s][dt][z][dh*4 + j][o%64][c%64].  A block is 128 (dt, z, dh, o, c) elements x 8
+// slot groups: group g sums the slots [g*S/8, (g+1)*S/8) of the four points in order (four independent chains), the group
+// sums are added in group order through LDS (reproducible), then the output transform.
+__global__ __launch_bounds__(1024) void conv_wgradw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S1,
+                                                                  int S0, int KT, int nob, int ncb, int Cout, int Cin,
+                                                                  int accumulate) {
+  __shared__ float sm[8][4][128];
+  const int g = threadIdx.y;
+  const long idx = (long)blockIdx.x * 128 + threadIdx.x;
+  const long per_s = (long)KT * nob * ncb * 12 * 4096;
+  const long total = (long)KT * nob * ncb * 3 * 4096;
+  long r = idx < total ? idx : total - 1;
+  const int c64 = r % 64; r /= 64;
+  const int o64 = r % 64; r /= 64;
+  const int dh = r % 3; r /= 3;
+  const int z = r % (nob * ncb); r /= (nob * ncb);
+  const int dt = (int)r;
+  const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 64 + c64;
+  const bool live = idx < total && o < Cout && c < Cin;
+  const int S = (KT == 3 && dt != 1) ? S0 : S1;  // slots that wrote a slab for this time tap
+  const float* p0 = part + (((long)dt * nob * ncb + z) * 12 + dh * 4) * 4096 + o64 * 64 + c64;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  if (live) {
+    const int hi = (int)((long)(g + 1) * S / 8);
+    for (int sl = (int)((long)g * S / 8); sl < hi; ++sl) {
+      const float* q = p0 + (long)sl * per_s;
+      m0 += q[0];
+      m1 += q[4096];
+      m2 += q[2 * 4096];
+      m3 += q[3 * 4096];
+    }
+  }
+  sm[g][0][threadIdx.x] = m0;
+  sm[g][1][threadIdx.x] = m1;
+  sm[g][2][threadIdx.x] = m2;
+  sm[g][3][threadIdx.x] = m3;
+  __syncthreads();
+  if (g == 0 && live) {
+    float m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = sm[0][j][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += sm[k][j][threadIdx.x];
+      m[j] = t;
+    }
+    const float hs = 0.5f * (m[1] + m[2]), hd = 0.5f * (m[1] - m[2]);
+    float* dst = dw + ((((long)o * Cin + c) * KT + dt) * 3 + dh) * 3;
+    const float g0 = m[0] + hs, g1 = hd, g2 = hs + m[3];
+    dst[0] = accumulate ? dst[0] + g0 : g0;
+    dst[1] = accumulate ? dst[1] + g1 : g1;
+    dst[2] = accumulate ? dst[2] + g2 : g2;
+  }
+}

@@ -41,6 +41,8 @@ _SIGS = {
     "hpvg_conv_bwd_weight_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_bwd_weight_wino_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_bwd_weight_wino_config": [I],
     "hpvg_channel_sum_ws_bytes": [I],
     "hpvg_channel_sum_f32": [P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_ws_bytes": [I],

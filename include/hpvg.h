@@ -80,6 +80,12 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
                              float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
                              int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
+/* Wide layers (Cin > 4 and Cout > 4) have a Winograd weight-gradient kernel behind the same entry point (the transpose of
+ * the forward F(2,3) along W: four products per pair of output columns and (dt, dh) instead of six, summed over all
+ * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never, 1 = by size, 2 = every wide
+ * layer; negative = query.  Returns the mode in force.  Host only. */
+int hpvg_conv_bwd_weight_wino_config(int mode);
+int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient.  accumulate != 0: out[c] += (the caller passes the parameter's
  * gradient buffer, which removes autograd's AccumulateGrad add kernel) */
 size_t hpvg_channel_sum_ws_bytes(int C);

@@ -164,6 +164,42 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
         assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
 
 
+@pytest.mark.parametrize("B,Cin,Cout,sp", [
+    (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 16, 24, (3, 4, 7)),
+    (1, 8, 8, (1, 1, 1)), (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (1, 5, 70, (2, 3, 300)),
+    (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),
+])
+def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(ops, B, Cin, Cout, sp):
+    """conv_wgradw_kernel (transposed F(2,3) along W, output transform in its reduce kernel; forced for every wide layer)
+    against the oracle and against the direct weight-gradient kernels on the same inputs: overwrite and accumulate forms,
+    odd / tiny widths, ragged channel counts, several 64-channel blocks, 2-D and 3-D."""
+    from hp_vae_gan_amd import lib as hplib
+    lib = hplib.load()
+    nd = len(sp)
+    x = _rand(B, Cin, *sp, seed=31)
+    gy = _rand(B, Cout, *sp, seed=32)
+    w = _rand(Cout, Cin, *([3] * nd), seed=33, scale=0.1).requires_grad_(True)
+    (want,) = torch.autograd.grad(O.conv(x, w, None), w, gy)
+    xd, gyd = x.to(DEV), gy.to(DEV)
+    base = _rand(*w.shape, seed=34).to(DEV)
+    prev = lib.hpvg_conv_bwd_weight_wino_config(-1)
+    res = {}
+    try:
+        for mode in (2, 0):
+            assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
+            dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
+            acc = base.clone()
+            assert ops.conv_bwd_weight_raw(gyd, xd, w.shape, into=acc) is None
+            res[mode] = (dw, acc)
+    finally:
+        lib.hpvg_conv_bwd_weight_wino_config(prev)
+    for mode, (dw, acc) in res.items():
+        tag = "wino." if mode == 2 else "direct."
+        assert_close(dw, want, RTOL, tag + "dw")
+        assert_close(acc - base, want, RTOL, tag + "dw.accumulate", atol=1e-5 * float(base.abs().max()))
+    assert_close(res[2][0], res[0][0], 3e-5, "wino-vs-direct.dw")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
 def test_conv_lrelu_epilogue_and_affine_prologue(ops, B, Cin, Cout, sp):
     nd = len(sp)

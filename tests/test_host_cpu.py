@@ -70,6 +70,25 @@ def test_winograd_conv_plan_geometry():
                     assert 2 * (NBP * 64 - 1) + 2 * RS + 3 < PL
 
 
+def test_winograd_weight_gradient_plan_geometry():
+    """The tile plan of conv_wgradw_kernel: even band width / row stride, channel strides 2 (mod 4) (8-byte pairs of a
+    half-wave's 32 channel rows in 32 different bank pairs), every read of the K loop inside its row, two buffers in LDS."""
+    lib = hplib.load()
+    out = (ctypes.c_int * 10)()
+    for KT, T in ((3, 5), (1, 1)):
+        for H in (1, 2, 9, 45, 144):
+            for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 230, 255, 256, 300]:
+                assert lib.hpvg_conv_bwd_weight_wino_plan(2, 64, 64, T, H, W, KT, out) == 0, (KT, H, W)
+                Th, Tw, nth, ntw, QK, S, DS, XS, lds, ntiles = list(out)
+                RS = Tw + 2
+                assert Tw % 2 == 0 and QK % 4 == 0 and QK >= Th * RS and DS % 4 == 2 and XS % 4 == 2
+                assert ntw * Tw >= W and (ntw - 1) * Tw < W and nth * Th >= H and (nth - 1) * Th < H
+                assert DS >= QK and XS >= QK + 2 * RS + 2 and XS >= (Th + 2) * RS      # furthest read: QK - 2 + 2*RS + 3
+                assert lds == 2 * 64 * (DS + XS) * 4 and lds <= 160 * 1024 and DS <= 512 and XS <= 512
+                assert ntiles == 2 * T * nth * ntw and 1 <= S <= 256
+                assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", 2, 64, 64, T, H, W, KT) >= 256 + S * KT * 12 * 4096 * 4
+
+
 def test_tables_match_reference():
     rows = json.load(open(os.path.join(GOLDEN, "tables.json")))
     for row in rows:
