@@ -75,6 +75,7 @@ struct ConvFwdArgs {
   // (tile, channel-chunk) items dealt evenly over the S workgroups (stream-K)
   int gridy, ntl, ndp, skbase;
   float* skpart;  // [S][2][MB*NB*16][256] raw accumulator slabs of partially computed tiles
+  int stagger;    // conv_wino_kernel: the workgroup in a CU's odd wave slot starts this many s_sleep(127) (~4 us each) late
 };
 
 template <int CP> struct AVecT;
@@ -1491,7 +1492,10 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
   a.skbase = a.ndp * S;
   a.skpart = (float*)ws;
   hipStream_t s = (hipStream_t)stream;
+  a.stagger = 0;
   if (wino) {
+    static const int stagger_env = [] { const char* e = getenv("HPVG_WINO_STAGGER"); return e ? atoi(e) : 0; }();
+    a.stagger = (S > HPVG_NUM_CU) ? stagger_env : 0;   // only when two workgroups share a CU
     a.wp = wp + direct_pack_floats(Cin, Cout, KT);   // the U fragments follow the direct pack
     return KT == 3 ? launch_wino<3>(a, p, S, s) : launch_wino<1>(a, p, S, s);
   }

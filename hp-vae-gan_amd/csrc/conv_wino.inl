@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
   const float* xl = xs + half * KT * PL + 2 * (l31 + 32 * nw);   // pair block i of this wave: + 128 * i floats
   const long astep = (long)a.mbtot * 64;                          // f32x4 elements between two tap-points
 
+  HPVG_TRACE_BEGIN
+  if (a.stagger > 0) {
+    // Two workgroups share a CU's matrix pipe and start together; their stage / compute phases then stay aligned (both
+    // stage, then both compute at half rate): a phase offset neither grows nor decays, so one is set here, once.
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: bit 0 of the wave slot tells the two apart
+    if (hwid & 1u)
+      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int S = gridDim.x;
   const int g = hpvg_xcd_remap(blockIdx.x, S);
   const long Isk = (long)(a.ntl - a.skbase) * a.nchunk;
@@ -50,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
   const int it_hi = (int)((long)(g + 1) * Isk / S);
   const int first_sk_tile = a.skbase + it / a.nchunk;
 
+  HPVG_PH_INIT
   bool first_stage = true;
   for (int k = 0;; ++k) {
     int tile, ch_lo, ch_hi;
@@ -83,10 +92,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
       if (!first_stage) __syncthreads();  // every wave is done reading the previous chunk
       first_stage = false;
+      HPVG_PH(3)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see conv_mfma_kernel (dead A prefetch vs the staging loop's registers)
+#ifdef HPVG_ABL_STAGE   // development ablation (timing only, wrong results): stage the first chunk of a tile only
+      if (ch == ch_lo)
+#endif
       conv_stage_chunk<CC, KT, false>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
+      HPVG_PH(0)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the asm LDS-DMA pieces are invisible to the compiler's counters
       __syncthreads();
+      HPVG_PH(1)
 
       const f32x4* wpt = reinterpret_cast<const f32x4*>(a.wp) + ((long)(ch * TH * 4) * a.mbtot + mt) * 64 + lane;
       f32x4 av[4];
@@ -104,8 +119,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
         for (int dh = 0; dh < 3; ++dh) {
           wpt += 4 * astep;
           f32x4 an[4];
+#ifdef HPVG_ABL_ALOAD   // development ablation (timing only, wrong results): no A-fragment loads inside the loop
+#pragma unroll
+          for (int j = 0; j < 4; ++j) an[j] = av[j];
+#else
 #pragma unroll
           for (int j = 0; j < 4; ++j) an[j] = wpt[j * astep];
+#endif
           const float* xt = xl + dt * PL + dh * RS;
           const float* xn = dh < 2 ? xl + dt * PL + (dh + 1) * RS : xl + (dt + 1 < KT ? dt + 1 : 0) * PL;
 #pragma unroll
@@ -132,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
           for (int j = 0; j < 4; ++j) av[j] = an[j];
         }
       }
+      HPVG_PH(2)
     }
 
     // ---- output transform in place: acc[0] <- y0 (even column of the pair), acc[1] <- y1 (odd column)
@@ -229,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
       }
     }
   }
+  HPVG_PH_END
+  HPVG_TRACE_END
 }
 
 // Finishes the tiles conv_wino_kernel computed in parts (the slabs hold output-transformed partial sums): one workgroup

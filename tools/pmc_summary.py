@@ -36,8 +36,10 @@ if json_out:
     # tools/perf_conv.py at that shape) + the largest stream-K fix-up launch that follows it
     import json
     rows = {k: 2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024 for k in set(f) | set(w)}
-    main = max((k for k in rows if "conv_mfma_kernel<8" in k[0] and k[0].rstrip(">").endswith(" 0")), key=lambda k: rows[k])
-    fix = max((k for k in rows if "conv_fixup_kernel" in k[0]), key=lambda k: rows[k])
+    # (the Winograd kernel when the library runs the shape on it - conv_wino_kernel<3, 2, 0> - else the direct one)
+    wino = [k for k in rows if "conv_wino_kernel<" in k[0] and k[0].rstrip(">").endswith(" 0")]
+    main = max(wino or [k for k in rows if "conv_mfma_kernel<8" in k[0] and k[0].rstrip(">").endswith(" 0")], key=lambda k: rows[k])
+    fix = max((k for k in rows if ("conv_wino_fixup_kernel" if wino else "conv_fixup_kernel") in k[0]), key=lambda k: rows[k])
     ent = {"shape": shape, "bytes": round(rows[main] + rows[fix]), "source": cite,
            "rows": {"%s grid %s" % main: round(rows[main]), "%s grid %s" % fix: round(rows[fix])}}
     json.dump({"note": "HBM bytes per launch of bench.py's roofline kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
