@@ -179,6 +179,30 @@ __device__ __forceinline__ void conv_dma_piece(const char* base_, unsigned voff,
       : "memory");
 }
 
+// The same for a 16-byte piece (global_load_lds_dwordx4: LDS destination = m0 + 16 * lane).  Neither the per-lane global
+// address nor the LDS base needs more than 4-byte alignment (tools/glds16_probe.hip, run on MI355X: correct for every
+// source and destination offset, no measurable cost).
+__device__ __forceinline__ void conv_dma_piece16(const char* base_, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+  const unsigned long long bb = (unsigned long long)base_;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32));
+  const unsigned long long base = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  unsigned long long keep_exec;
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b32 %1, m0\n\t"
+      "s_mov_b64 exec, %3\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(keep_exec), "=&s"(keep_m0)
+      : "v"(voff), "s"(mask), "s"(lds_addr), "s"(base)
+      : "memory");
+}
+
 // Stage channel chunk `ch` (CC channels x KT time planes) of the tile of sample b / output plane t into xs.
 template <int CC, int KT, bool PRO>
 __device__ __forceinline__ void conv_stage_chunk(const ConvFwdArgs& a, float* xs, const StageSlots& sl, int ch, bool first_chunk,
@@ -1003,6 +1027,7 @@ inline size_t direct_pack_floats(int Cin, int Cout, int KT) {
 struct Plan {
   int Th, Tw, RS, PL, L, qstride, nrange, ntw, nblocks, NB, MB, gridy, nj;  // Th != 0 only for the narrow kernel's 2-D tiles
   size_t lds;  // bytes of the LDS tile buffer
+  int stg;     // conv_wino_kernel: 2 = rows-as-in-memory staging with 16-byte pieces (conv_wino.inl), else the halo'd bands
 };
 
 constexpr long CONV_SLOTS = 2L * HPVG_NUM_CU;  // co-resident workgroups: two per CU (256 VGPRs each, LDS <= 80 KB)
@@ -1148,6 +1173,21 @@ Plan plan_wino_search(int B, int Cin, int Cout, int T, int H, int W, int KT, boo
   Plan best{};
   double best_cost = 1e300;
   const int Lmax = WINO_NBP * 128;
+  if (g_wino_stg != 1 && (W & 1) == 0 && W >= 2) {
+    // staging form 2: one band of the full width, row stride W, no halo columns, a quarter of the staging instructions.
+    // Measured (profiles/r02_perf_wino_stg2.txt): -4.2 % at stage 9, -3.7 % at stage 8, +-1-2 % at stages 5-7, where a
+    // workgroup sees fewer than two whole tiles: taken from two tiles per co-resident workgroup up (or when forced).
+    const long flat = (long)H * W;
+    const int nrange = hpvg_cdiv(flat, Lmax);
+    int L = hpvg_cdiv(flat, nrange);
+    L += L & 1;
+    const int PL = 2 * W + Lmax + 8;                          // reads reach sh + 2 * (Lmax/2 - 1) + 2 * W + 3 <= 2 W + Lmax + 5
+    const size_t lds = (size_t)WINO_CC * KT * PL * sizeof(float);
+    const int ngmax = (L + 2 * W + 2 + 3 + 3) >> 2;           // 16-byte groups of the staged span: one per lane
+    const long ntl = (long)B * T * nrange * gridy;
+    if (lds <= 80 * 1024 && ngmax <= 256 && (g_wino_stg == 2 || ntl >= 2 * CONV_SLOTS))
+      return Plan{0, W, W, PL, L, L, nrange, 1, hpvg_cdiv(L, 32), WINO_NBP, 2, gridy, 1, lds, 2};
+  }
   int prev_tw = 0;
   for (int ntw = 1; ntw <= W; ++ntw) {
     int Tw = hpvg_cdiv(W, ntw);
@@ -1211,6 +1251,8 @@ inline bool conv_use_wino(int B, int Cin, int Cout, int T, int H, int W, int KT,
     g_wino_mode = wino_env_mode();
     const char* e = getenv("HPVG_WINO_MIN");
     if (e) g_wino_min_pos = atol(e);
+    const char* f = getenv("HPVG_WINO_STG");   // staging form: 1 = halo'd bands only, 2 = rows-as-in-memory wherever it fits
+    if (f) g_wino_stg = atoi(f) == 1 ? 1 : (atoi(f) == 2 ? 2 : 0);
   }
   if (g_wino_mode == 0) return false;
   if (g_wino_mode == 2) return true;
@@ -1230,7 +1272,7 @@ Plan plan_conv(int B, int Cin, int Cout, int T, int H, int W, int KT, bool strea
   constexpr int NSLOT = 2048;
   static thread_local Entry cache[NSLOT];
   static thread_local int filled = 0;
-  const Key k{B, Cin, Cout, T, H, W, KT, (streamk ? 1 : 0) | (wino ? 2 : 0)};
+  const Key k{B, Cin, Cout, T, H, W, KT, (streamk ? 1 : 0) | (wino ? 2 : 0) | (wino ? g_wino_stg << 2 : 0)};
   unsigned h = 2166136261u;
   for (int v : {B, Cin, Cout, T, H, W, KT, k.sk}) h = (h ^ (unsigned)v) * 16777619u;
   for (int probe = 0; probe < NSLOT; ++probe) {
@@ -1299,10 +1341,10 @@ int dispatch_conv(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   }
 }
 
-template <int KT, int VAR>
+template <int KT, int VAR, int STG>
 int launch_wino_var(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_wino_kernel<KT, WINO_NBP, VAR>;
+  auto kern = conv_wino_kernel<KT, WINO_NBP, VAR, STG>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
@@ -1320,11 +1362,15 @@ int launch_wino_var(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
   return rc;
 }
 
+template <int KT, int STG>
+int launch_wino_stg(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
+  if (a.mask || a.mask_bits) return launch_wino_var<KT, VAR_MASK, STG>(a, p, S, s);
+  if (a.bits_out) return launch_wino_var<KT, VAR_BITS, STG>(a, p, S, s);
+  return launch_wino_var<KT, VAR_PLAIN, STG>(a, p, S, s);
+}
 template <int KT>
 int launch_wino(const ConvFwdArgs& a, const Plan& p, int S, hipStream_t s) {
-  if (a.mask || a.mask_bits) return launch_wino_var<KT, VAR_MASK>(a, p, S, s);
-  if (a.bits_out) return launch_wino_var<KT, VAR_BITS>(a, p, S, s);
-  return launch_wino_var<KT, VAR_PLAIN>(a, p, S, s);
+  return p.stg == 2 ? launch_wino_stg<KT, 2>(a, p, S, s) : launch_wino_stg<KT, 1>(a, p, S, s);
 }
 
 template <int KT>
@@ -1536,9 +1582,12 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
 int hpvg_conv_wino_config(int mode, long min_positions) {
   if (wino_env_mode() == 0) return HPVG_ERR_UNSUPPORTED;
   (void)conv_use_wino(1, 8, 64, 1, 1, 1, 3, false);   // settle the defaults
-  if (mode >= 0) g_wino_mode = mode > 2 ? 2 : mode;
+  if (mode >= 0) {
+    g_wino_mode = mode > 2 ? 2 : mode;
+    g_wino_stg = mode == 3 ? 2 : (mode == 4 ? 1 : 0);   // 3 / 4: every eligible launch AND one staging form forced (tests)
+  }
   if (min_positions >= 0) g_wino_min_pos = min_positions;
-  return g_wino_mode;
+  return g_wino_mode == 2 && g_wino_stg ? (g_wino_stg == 2 ? 3 : 4) : g_wino_mode;
 }
 
 // Debug/introspection: the tile plan conv_wino_kernel would run this shape with (whether or not the launch picks it):

@@ -27,7 +27,87 @@ typedef float f32x2u4 __attribute__((ext_vector_type(2), aligned(4)));  // 8-byt
 constexpr int WINO_CC = 8;
 constexpr int WINO_NBP = 2;
 
-template <int KT, int NBP, int VAR>
+// ---- Staging, second form (STG = 2): the rows as they lie in memory.
+// With ONE band of the full (even) width the inputs of a tile - flattened positions [q0 - W - 1, q0 + L + W] of each
+// (channel, time) plane - are one contiguous span of global memory, so the LDS image of a plane is a verbatim copy of it
+// (row stride W, NO halo columns: no junk GEMM columns either) and is filled by 16-BYTE LDS-DMA pieces: lane g of the
+// workgroup moves elements [base + 4g, base + 4g + 4), base = the span start rounded down to a multiple of 4 (groups then
+// never straddle the start of the plane) - 24 pieces per chunk and wave instead of 72-96 dword pieces.  The image sits one
+// float into its plane slot, which makes the first input of a tile's first pair 8-byte aligned (`sh` is 2 or 4).  What the
+// halo columns did is done by two per-lane constants instead: a pair at the left image border must see d0 = 0 and a pair at
+// the right border d3 = 0 (the image holds the neighbouring ROW's element there); they are folded into the input transform
+// (V0 = f0 d0 - d2, V3 = d1 - f3 d3: one fma each instead of one subtraction).  Rows above / below the image are positions
+// outside [0, H W): never loaded, zeroed once per tile; a group cut by the END of the plane (H W not a multiple of 4) is
+// loaded by a dword piece of at most three lanes.
+struct StageSlots2 {
+  unsigned bofs;               // byte offset of this lane's group inside a plane (lanes of em4)
+  unsigned long long em4;      // lanes of this wave whose group lies wholly inside the plane
+  unsigned long long em1;      // wave 0: lanes of the dword piece for the group cut by the plane end
+  unsigned tofs;               // its per-lane byte offset inside the plane
+  int tl;                      // ... and where that group starts in the plane image (floats)
+  int i0;                      // first element of this lane's group
+  int sh;                      // image offset of the tile's first input (q0 - W - 1): 2 or 4
+  bool span;                   // this lane's group belongs to the staged span
+};
+__device__ __forceinline__ StageSlots2 wino_stage_slots2(const ConvFwdArgs& a, int q0, int tid, int wave) {
+  StageSlots2 s;
+  const int HWp = a.H * a.W;
+  const int s0 = q0 - a.W - 1;                                   // odd: q0 and W are even
+  const int base = s0 >= 0 ? (s0 & ~3) : -((3 - s0) & ~3);       // floor to a multiple of 4
+  s.sh = s0 - base + 1;
+  const int ng = (q0 + a.L + a.W + 1 - base + 3) >> 2;           // valid lanes read up to element q0 + L + W
+  s.i0 = base + 4 * tid;
+  s.span = tid < ng;
+  const bool full = s.span && s.i0 >= 0 && s.i0 + 4 <= HWp;
+  s.bofs = full ? (unsigned)s.i0 * 4u : 0u;
+  s.em4 = __ballot(full);
+  const int gt = (HWp - base) >> 2;                              // the group that holds element H*W
+  const int r = HWp - (base + 4 * gt);                           // its elements inside the plane
+  const bool tail = r > 0 && gt < ng;
+  s.em1 = (tail && wave == 0) ? ((1ull << r) - 1ull) : 0ull;
+  s.tofs = (unsigned)(HWp - r + (tid & 63)) * 4u;
+  s.tl = 4 * gt;
+  return s;
+}
+
+template <int CC, int KT>
+__device__ __forceinline__ void wino_stage_chunk2(const ConvFwdArgs& a, float* xs, const StageSlots2& sl, int ch, bool first_chunk,
+                                                  int b, int t, int tid, int wave) {
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int HWp = a.H * a.W;
+  const long HWb = (long)HWp * 4;
+  const int PL = a.PL;
+  const char* cbase = reinterpret_cast<const char*>(a.x) + (((long)b * a.Cin + (long)ch * CC) * a.T + (t - (KT == 3 ? 1 : 0))) * HWb;
+  int pl = 0;
+#pragma unroll 1
+  for (int c = 0; c < CC; ++c, cbase += (long)a.T * HWb)
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt, ++pl) {
+      const int cg = ch * CC + c;
+      const int tt = t + dt - (KT == 3 ? 1 : 0);
+      const bool valid = cg < a.Cin && tt >= 0 && tt < a.T;
+      float* img = xs + pl * PL + 1;          // element base + k of the plane at img[k]
+      if (valid) {
+        const char* src = cbase + dt * HWb;
+        if (sl.em4 != 0ull) conv_dma_piece16(src, sl.bofs, (unsigned)(size_t)(lptr_t)(img + wave * 256), sl.em4);
+        if (sl.em1 != 0ull) conv_dma_piece(src, sl.tofs, (unsigned)(size_t)(lptr_t)(img + sl.tl), sl.em1);
+        if (first_chunk && sl.span) {
+          // positions outside the plane (rows -1 and H) are never written by a load: zero them once per tile
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (sl.i0 + e < 0 || sl.i0 + e >= HWp) img[4 * tid + e] = 0.f;
+        }
+      } else if (first_chunk || cg >= a.Cin) {
+        // a plane outside the clip (t) stays zero for the whole tile; a channel past Cin only exists in the last chunk
+        if (sl.span) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) img[4 * tid + e] = 0.f;
+        }
+      }
+    }
+}
+
+template <int KT, int NBP, int VAR, int STG>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) {
   constexpr int CC = WINO_CC, CP = CC / 2;
   constexpr int TH = KT * 3;  // (dt, dh) steps per chunk, four tap-points each
@@ -40,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
   const int mw = wave & 1, nw = wave >> 1;
   const long HW = (long)a.H * a.W;
   const int RS = a.RS, PL = a.PL;
-  const float* xl = xs + half * KT * PL + 2 * (l31 + 32 * nw);   // pair block i of this wave: + 128 * i floats
+  const float* xl0 = xs + half * KT * PL + 2 * (l31 + 32 * nw);  // pair block i of this wave: + 128 * i floats
   const long astep = (long)a.mbtot * 64;                          // f32x4 elements between two tap-points
 
   HPVG_TRACE_BEGIN
@@ -79,7 +159,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
     const int b = tc.b, t = tc.t, q0 = tc.q0, w0 = tc.w0;
     const int mt = tc.mb0 + mw;   // this wave's m-tile (32 output channels)
 
-    const StageSlots sl = conv_stage_slots(a, q0, w0, tid);
+    StageSlots sl;
+    StageSlots2 sl2;
+    const float* xl = xl0;
+    float f0[NBP], f3[NBP];     // STG 2: 0 where the pair's d0 / d3 lies outside the image row, else 1
+    if constexpr (STG == 2) {
+      sl2 = wino_stage_slots2(a, q0, tid, wave);
+      xl = xl0 + sl2.sh;
+#pragma unroll
+      for (int i = 0; i < NBP; ++i) {
+        const int Q = q0 + 2 * ((nw + 2 * i) * 32 + l31);
+        const int gw = Q - (Q / RS) * RS;
+        f0[i] = gw == 0 ? 0.f : 1.f;
+        f3[i] = gw + 2 >= a.W ? 0.f : 1.f;
+      }
+    } else {
+      sl = conv_stage_slots(a, q0, w0, tid);
+    }
 
     f32x16 acc[4][NBP];
 #pragma unroll
@@ -97,7 +193,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
 #ifdef HPVG_ABL_STAGE   // development ablation (timing only, wrong results): stage the first chunk of a tile only
       if (ch == ch_lo)
 #endif
-      conv_stage_chunk<CC, KT, false>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
+      {
+        if constexpr (STG == 2) wino_stage_chunk2<CC, KT>(a, xs, sl2, ch, ch == ch_lo, b, t, tid, wave);
+        else conv_stage_chunk<CC, KT, false>(a, xs, sl, ch, ch == ch_lo, b, t, tid, wave);
+      }
       HPVG_PH(0)
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the asm LDS-DMA pieces are invisible to the compiler's counters
       __syncthreads();
@@ -143,7 +242,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
 #pragma unroll
               for (int i = 0; i < NBP; ++i) {
                 const f32x2a d01 = r0[cp & 1][i], d23 = r1[cp & 1][i];
-                const float v = j == 0 ? d01[0] - d23[0] : (j == 1 ? d01[1] + d23[0] : (j == 2 ? d23[0] - d01[1] : d01[1] - d23[1]));
+                float v;
+                if constexpr (STG == 2)
+                  v = j == 0 ? __builtin_fmaf(f0[i], d01[0], -d23[0])
+                             : (j == 1 ? d01[1] + d23[0] : (j == 2 ? d23[0] - d01[1] : __builtin_fmaf(-f3[i], d23[1], d01[1])));
+                else
+                  v = j == 0 ? d01[0] - d23[0] : (j == 1 ? d01[1] + d23[0] : (j == 2 ? d23[0] - d01[1] : d01[1] - d23[1]));
                 acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][cp], v, acc[j][i], 0, 0, 0);
               }
             __builtin_amdgcn_s_setprio(0);
@@ -350,6 +454,7 @@ inline int wino_env_mode() {
 }
 int g_wino_mode = -1;          // -1: not configured yet, take the environment's
 long g_wino_min_pos = -1;
+int g_wino_stg = 0;            // staging form of conv_wino_kernel: 0 = by size, 1 = halo'd bands only, 2 = rows-as-in-memory wherever it fits
 inline bool conv_is_wino(int Cin, int Cout) { return wino_env_mode() != 0 && Cin >= 8 && Cout > 32; }
 inline size_t wino_pack_floats(int Cin, int Cout, int KT) {
   const int nchunk = hpvg_cdiv(Cin, WINO_CC);

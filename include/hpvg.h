@@ -64,8 +64,10 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
  * (four products per output pair and (dt, dh) instead of six, summed over the channels before the output transform: 2/3 of
  * the matrix-core work; fp32, ~1e-6 of the output scale away from the direct kernel).  The weight pack carries both forms;
  * which kernel a launch runs is decided per shape.  hpvg_conv_wino_config: mode 0 = direct kernel only, 1 = Winograd from
- * `min_positions` output positions (B*T*H*W) up, 2 = every eligible launch; a negative argument leaves that setting as it
- * is; returns the mode in force (HPVG_ERR_UNSUPPORTED when the process was started with HPVG_WINO=0).  Host only. */
+ * `min_positions` output positions (B*T*H*W) up, 2 = every eligible launch (3 / 4: the same with the kernel's staging form
+ * forced - rows as they lie in memory with 16-byte LDS-DMA pieces / halo'd bands with dword pieces; otherwise by size); a
+ * negative argument leaves that setting as it is; returns the mode in force (HPVG_ERR_UNSUPPORTED when the process was
+ * started with HPVG_WINO=0).  Host only. */
 int hpvg_conv_wino_config(int mode, long min_positions);
 /* host only: the Winograd kernel's tile plan: out[0..9] = L, Tw, nrange, ntw, RS, pair blocks per wave, m-tiles per
  * workgroup, gridy, lds_bytes, ntiles */

@@ -101,6 +101,10 @@ def wino_mode():
     (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 16, 40, (3, 4, 7)),
     (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (2, 64, 64, (5, 45, 81)), (1, 64, 64, (1, 1, 1)),
     (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),
+    # even widths run the rows-as-in-memory staging (16-byte LDS-DMA pieces, border factors in the input transform):
+    # H*W = 2 (mod 4) exercises the dword piece for the group cut by the plane end; W = 2: every pair is at both borders
+    (2, 64, 64, (3, 57, 102)), (1, 64, 64, (7, 91, 162)), (2, 16, 40, (2, 3, 2)), (1, 64, 64, (2, 1, 258)), (2, 64, 64, (45, 82)),
+    (1, 64, 64, (3, 400)),   # too wide for one 16-byte group per lane: back to the halo'd bands
 ])
 def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
     """conv_wino_kernel (F(2,3) along W; every eligible launch forced onto it) against the oracle and against the direct
@@ -120,7 +124,9 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
     act = O.leaky_relu(want)
     xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
     res = {}
-    for mode in (2, 0):
+    # 3 / 4: every eligible launch on the Winograd kernel with the rows-as-in-memory staging (16-byte pieces; even widths
+    # that fit, else it falls back to the bands) / with the halo'd bands; 0: the direct kernel
+    for mode in (3, 4, 0):
         wino_mode(mode)
         y = ops.conv_fwd_raw(xd, wd, bd)
         dx = ops.conv_fwd_raw(gyd, wd, None, flip=True)
@@ -137,7 +143,7 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
                    ctypes.c_size_t(0), Bq, Cin, Cout, T, H, W, KT, hplib.stream())
         res[mode] = dict(y=y, dx=dx, ya=ya, bits=bits, dxm_bits=dxm_bits, dxm_f32=dxm_f32, y_pl=y_pl, xbits_src=xbits_src)
     for mode, r in res.items():
-        tag = "wino." if mode == 2 else "direct."
+        tag = {3: "wino.rows.", 4: "wino.bands.", 0: "direct."}[mode]
         assert_close(r["y"], want, RTOL, tag + "y")
         assert_close(r["y_pl"], want, RTOL, tag + "y.plain-launch")
         assert_close(r["dx"], want_dx, RTOL, tag + "dx")
@@ -147,21 +153,22 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
         m = torch.where(r["xbits_src"] > 0, 1.0, 0.2)
         assert_close(r["dxm_bits"], r["dx"] * m, 1e-6, tag + "dx.mask_bits")
     # Winograd against the direct kernel: rounding only (measured ~1e-6 of the output scale)
-    for k in ("y", "dx", "ya", "y_pl", "dxm_f32"):
-        assert_close(res[2][k], res[0][k], 2e-5, "wino-vs-direct." + k)
-    # the sign bits agree wherever the activation is not within rounding of zero
     far = (want.abs() > 1e-4 * float(want.abs().max())).to(DEV)
-    sa, sb = res[2]["ya"] > 0, res[0]["ya"] > 0
-    assert bool(((sa == sb) | ~far).all())
     cw = hplib.call("hpvg_conv_mask_words", B, Cout, *((ops.geom(xd))[2:]))
-    assert res[2]["bits"].numel() == cw
-    # bits written by the Winograd epilogue decode to the sign of its own output
     mt = (Cout + 31) // 32
-    bw = res[2]["bits"].view(B, -1, mt).cpu()
-    yw = res[2]["ya"].reshape(B, Cout, -1).cpu()
-    for c in (0, Cout // 2, Cout - 1):
-        got = (bw[:, :, c // 32] >> (c % 32)) & 1
-        assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
+    for wm in (3, 4):
+        for k in ("y", "dx", "ya", "y_pl", "dxm_f32"):
+            assert_close(res[wm][k], res[0][k], 2e-5, "wino%d-vs-direct.%s" % (wm, k))
+        # the sign bits agree wherever the activation is not within rounding of zero
+        sa, sb = res[wm]["ya"] > 0, res[0]["ya"] > 0
+        assert bool(((sa == sb) | ~far).all())
+        assert res[wm]["bits"].numel() == cw
+        # bits written by the Winograd epilogue decode to the sign of its own output
+        bw = res[wm]["bits"].view(B, -1, mt).cpu()
+        yw = res[wm]["ya"].reshape(B, Cout, -1).cpu()
+        for c in (0, Cout // 2, Cout - 1):
+            got = (bw[:, :, c // 32] >> (c % 32)) & 1
+            assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
 
 
 @pytest.mark.parametrize("B,Cin,Cout,sp", [

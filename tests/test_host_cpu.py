@@ -46,28 +46,45 @@ def test_size_queries_and_plans_run_without_gpu():
 
 
 def test_winograd_conv_plan_geometry():
-    """The tile plan of conv_wino_kernel over every width: even band width and row stride (an output pair never straddles a
-    row or a band), even tile length within the accumulator blocks, every output position covered, every LDS read of a
-    lane inside the tile buffer, the staged plane within the 4 x 256 staging slots."""
+    """The tile plan of conv_wino_kernel over every width, both staging forms (halo'd bands for odd or very wide images, rows
+    as they lie in memory for even widths): even band width and row stride (an output pair never straddles a row or a
+    band), even tile length within the accumulator blocks, every output position covered, every LDS read of a lane inside
+    the tile buffer, the staged plane within the staging slots / one 16-byte group per lane."""
     lib = hplib.load()
     out = (ctypes.c_int * 10)()
     assert lib.hpvg_conv_wino_plan(2, 3, 64, 5, 9, 16, 3, out) != 0     # Cin < 8: direct kernel
     assert lib.hpvg_conv_wino_plan(2, 64, 32, 5, 9, 16, 3, out) != 0    # one m-tile: direct kernel
-    for KT, T in ((3, 5), (1, 1)):
+    prev = lib.hpvg_conv_wino_config(-1, -1)
+    seen = set()
+    for mode, KT, T in ((3, 3, 5), (3, 1, 1), (1, 3, 5), (4, 3, 5)):   # 3 / 4: one staging form forced, 1: the planner's own pick
+        assert lib.hpvg_conv_wino_config(mode, -1) == mode
         for H in (1, 2, 9, 45, 144):
-            for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 230, 255, 256, 300]:
+            for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 230, 255, 256, 284, 286, 300, 380, 382, 640]:
                 for Cout in (64, 70, 128):
                     assert lib.hpvg_conv_wino_plan(2, 64, Cout, T, H, W, KT, out) == 0, (KT, H, W)
+                    seen.add((mode, out[4] == out[1]))
+                    assert mode != 4 or out[4] != out[1]
                     L, Tw, nrange, ntw, RS, NBP, MBW, gridy, lds, ntiles = list(out)
-                    assert Tw % 2 == 0 and RS == Tw + 2 and L % 2 == 0 and 2 <= L <= NBP * 128
+                    assert L % 2 == 0 and 2 <= L <= NBP * 128
+                    assert gridy * MBW * 32 >= Cout and ntiles == 2 * T * nrange * ntw * gridy and lds <= 80 * 1024
+                    if RS == Tw:
+                        # staging form 2: one band of the full (even) width, rows as they lie in memory, 16-byte pieces
+                        assert W % 2 == 0 and Tw == W and ntw == 1 and nrange * L >= H * W
+                        PL = 2 * W + NBP * 128 + 8
+                        assert lds == 8 * KT * PL * 4
+                        assert (L + 2 * W + 2 + 6) // 4 <= 256             # one 16-byte group per lane
+                        assert 4 + 2 * (NBP * 64 - 1) + 2 * W + 3 < PL      # furthest read of a lane (image offset <= 4)
+                        continue
+                    assert Tw % 2 == 0 and RS == Tw + 2
                     assert ntw * Tw >= W and (ntw - 1) * Tw < W
                     assert nrange * L >= (H - 1) * RS + Tw                 # every output position of a band plane
-                    assert gridy * MBW * 32 >= Cout and ntiles == 2 * T * nrange * ntw * gridy
                     PL = NBP * 128 + 2 * RS + 2
-                    assert lds == 8 * KT * PL * 4 and lds <= 80 * 1024
+                    assert lds == 8 * KT * PL * 4
                     assert L + 2 * RS + 2 <= 1024                          # staged positions per plane
                     # furthest read of a lane: pair NBP*64 - 1, row tap 2, inputs d2 d3
                     assert 2 * (NBP * 64 - 1) + 2 * RS + 3 < PL
+    lib.hpvg_conv_wino_config(prev, -1)
+    assert {(3, True), (3, False), (1, True), (1, False), (4, False)} <= seen   # both forms met, forced and picked
 
 
 def test_winograd_weight_gradient_plan_geometry():
