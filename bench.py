@@ -412,9 +412,13 @@ def main():
             mode = hplib.load().hpvg_conv_wino_config(-1, -1)
             wmin = os.environ.get("HPVG_WINO_MIN")
             wino = mode == 2 or (mode == 1 and B * T * H * W >= (int(wmin) if wmin else (0 if KT == 3 else 24000)))
-            kname = ("conv_wino_kernel + conv_wino_fixup_kernel (64->64 %s fwd, Winograd F(2,3) along W, stream-K, fp32 v_mfma_f32_32x32x2_f32)"
+            wino2 = wino and hplib.load().hpvg_conv_wants_wino2d(B, 64, 64, T, H, W, KT) == 1
+            kname = ("conv_wino2d_kernel (64->64 %s fwd, Winograd F(2x2,3x3) over H and W, one software-pipelined workgroup per CU, fp32 v_mfma_f32_32x32x2_f32)"
+                     if wino2 else
+                     "conv_wino_kernel + conv_wino_fixup_kernel (64->64 %s fwd, Winograd F(2,3) along W, stream-K, fp32 v_mfma_f32_32x32x2_f32)"
                      if wino else "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)") % ("3x3x3" if KT == 3 else "3x3")
-            executed = flops * (2.0 / 3.0 if wino else 1.0)
+            # matrix-core flops the kernel executes per algorithmic flop: 1 direct, 2/3 one-axis Winograd, 4/9 two-axis
+            executed = flops * (4.0 / 9.0 if wino2 else (2.0 / 3.0 if wino else 1.0))
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

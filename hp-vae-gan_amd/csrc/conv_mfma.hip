@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
 }
 
 #include "conv_wino.inl"
+#include "conv_wino2d.inl"
 
 // ------------------------------------------------------------------------------------------
 // Narrow-output convolution (Cout <= 4): the tails 64->3 / 64->1 (networks_3d.py:175,341,362) and the backward-data
@@ -951,7 +952,10 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   if (idx >= total_direct) {
-    float val = wino_pack_value(w, idx - total_direct, Cin_k, Cout_k, taps / 9, (Cin_k + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip);
+    const long iw = idx - total_direct;
+    const long nw1 = ((long)((Cin_k + WINO_CC - 1) / WINO_CC) * (taps / 9) * 3 * 4 + 4) * mbtot * 64 * (WINO_CC / 2);   // wino_pack_floats
+    float val = iw < nw1 ? wino_pack_value(w, iw, Cin_k, Cout_k, taps / 9, (Cin_k + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip)
+                         : wino2_pack_value(w, iw - nw1, Cin_k, Cout_k, (Cin_k + 3) / 4, 2 * ((mbtot + 1) / 2), transpose_flip);
     if (inv_scale) val *= inv_scale[0];
     wp[idx] = val;
     return;
@@ -991,7 +995,10 @@ __global__ void conv_pack_batch_kernel(const PackBatchArgs a, int C, int taps, i
   const float* __restrict__ w = a.w[it];
   const int transpose_flip = a.flip[it];
   if (idx >= total_direct) {
-    a.wp[it][idx] = wino_pack_value(w, idx - total_direct, C, C, taps / 9, (C + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip);
+    const long iw = idx - total_direct;
+    const long nw1 = ((long)((C + WINO_CC - 1) / WINO_CC) * (taps / 9) * 3 * 4 + 4) * mbtot * 64 * (WINO_CC / 2);   // wino_pack_floats
+    a.wp[it][idx] = iw < nw1 ? wino_pack_value(w, iw, C, C, taps / 9, (C + WINO_CC - 1) / WINO_CC, mbtot, transpose_flip)
+                             : wino2_pack_value(w, iw - nw1, C, C, (C + 3) / 4, 2 * ((mbtot + 1) / 2), transpose_flip);
     return;
   }
   const int CP = CC / 2;
@@ -1260,6 +1267,48 @@ inline bool conv_use_wino(int B, int Cin, int Cout, int T, int H, int W, int KT,
   return (long)B * T * H * W >= min_pos;
 }
 
+// The two-axis Winograd kernel (conv_wino2d.inl): where it can run and where it is taken.  g_wino2d: 0 = by size, 1 = never,
+// 2 = wherever it can run (hpvg_conv_wino_config modes 5 / 6 set 2 / 1).
+int g_wino2d = 0;
+struct W2Geom { int Cq, R, ntq, tqw, gridy, nsc, ntl; bool ok; };
+inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  W2Geom q{};
+  if (!conv_is_wino2d(Cin, Cout, KT) || (W & 1) || (((long)H * W) & 3) || W < 2) return q;
+  q.Cq = W / 2;
+  q.R = hpvg_cdiv(H, 2);
+  q.ntq = hpvg_cdiv(q.Cq, 64);
+  q.tqw = hpvg_cdiv(q.Cq, q.ntq);
+  if (3 * W + 2 * q.tqw + 8 > 1024) return q;          // the staged span of a tile: one 16-byte group per lane
+  q.gridy = hpvg_cdiv(hpvg_cdiv(Cout, 32), 2);
+  q.nsc = hpvg_cdiv(Cin, 4);
+  const long ntl = (long)B * T * q.R * q.ntq * q.gridy;
+  if (ntl > 0x7fffffffL) return q;
+  q.ntl = (int)ntl;
+  q.ok = true;
+  return q;
+}
+// Taken by size where it was measured to win (tools/perf_wino.py, profiles/r02_perf_wino2d.txt): whole tiles, one
+// workgroup per CU and no stream-K need >= 8 rounds of tiles, and a tile must fill most of its 64 quads - stage 9 (64 of 64,
+// 14.6 rounds): 1.14 vs 1.31 ms for the one-axis kernel + fix-up; stage 8 (51 of 64 quads, 5 rounds): 0.53 vs 0.46.
+constexpr long W2_MIN_TILES = 8L * HPVG_NUM_CU;
+inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
+  if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
+  return g_wino2d == 2 || (q.ntl >= W2_MIN_TILES && q.tqw >= 56);
+}
+template <int VAR>
+int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_wino2d_kernel<VAR>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  const int S = a.ntl < HPVG_NUM_CU ? a.ntl : HPVG_NUM_CU;
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), (size_t)2 * 12 * W2_PL * sizeof(float), s, a);
+  return hpvg_launch_status();
+}
+
 // The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).
 inline bool conv_is_narrow(int Cin, int Cout) { return Cout <= 4 && Cin > 4; }
 
@@ -1407,21 +1456,46 @@ inline size_t conv_sk_ws_bytes(const Plan& p, int S) { return (size_t)S * 2 * p.
 extern "C" {
 
 // number of floats of the packed-weight buffer for a conv with Cin -> Cout (kernel view)
-size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) {
+static size_t wpack_floats_impl(int Cin, int Cout, int KT, bool with2d) {
   if (conv_is_narrow(Cin, Cout)) return (size_t)hpvg_cdiv(Cin * KT, 2) * hpvg_cdiv(9 * Cout, 32) * 64;  // wn[kstep][ntile][lane]
-  return direct_pack_floats(Cin, Cout, KT) + (conv_is_wino(Cin, Cout) ? wino_pack_floats(Cin, Cout, KT) : 0);
+  return direct_pack_floats(Cin, Cout, KT) + (conv_is_wino(Cin, Cout) ? wino_pack_floats(Cin, Cout, KT) : 0) +
+         (with2d && conv_is_wino2d(Cin, Cout, KT) ? wino2_pack_floats(Cin, Cout) : 0);
 }
+// does a launch of this geometry run the two-axis Winograd kernel (and therefore read the pack's third section)?
+static bool wants_wino2d(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (B < 1 || T < 1 || H < 1 || W < 1 || !conv_use_wino(B, Cin, Cout, T, H, W, KT, false)) return false;
+  return conv_use_wino2d(wino2d_geom(B, Cin, Cout, T, H, W, KT), false);
+}
+// A pack made WITHOUT a geometry serves every launch of the layer (all sections); the _for forms leave out the two-axis
+// Winograd fragments (786 KB for 64 -> 64 x 27) unless a launch of the given geometry (kernel view: the conv's input
+// B, T, H, W) reads them, and are valid for launches of that geometry only.
+size_t hpvg_conv_wpack_floats(int Cin, int Cout, int KT) { return wpack_floats_impl(Cin, Cout, KT, true); }
+size_t hpvg_conv_wpack_floats_for(int Cin, int Cout, int KT, int B, int T, int H, int W) {
+  return wpack_floats_impl(Cin, Cout, KT, wants_wino2d(B, Cin, Cout, T, H, W, KT));
+}
+int hpvg_conv_wants_wino2d(int B, int Cin, int Cout, int T, int H, int W, int KT) { return wants_wino2d(B, Cin, Cout, T, H, W, KT) ? 1 : 0; }
 
 // w: natural layout of the LAYER weight [Cout_layer][Cin_layer][KT][3][3].
 // transpose_flip = 0: pack for the forward conv (kernel Cin=Cin_layer, Cout=Cout_layer)
 // transpose_flip = 1: pack for backward-data (kernel Cin=Cout_layer, Cout=Cin_layer)
+static int pack_weight_impl(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                            int transpose_flip, bool with2d, void* stream);
 int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
                               int transpose_flip, void* stream) {
+  return pack_weight_impl(w, inv_scale, wp, Cin_layer, Cout_layer, KT, transpose_flip, true, stream);
+}
+int hpvg_conv_pack_weight_for_f32(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                                  int transpose_flip, int B, int T, int H, int W, void* stream) {
+  const int Cin_k = transpose_flip ? Cout_layer : Cin_layer, Cout_k = transpose_flip ? Cin_layer : Cout_layer;
+  return pack_weight_impl(w, inv_scale, wp, Cin_layer, Cout_layer, KT, transpose_flip, wants_wino2d(B, Cin_k, Cout_k, T, H, W, KT), stream);
+}
+static int pack_weight_impl(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                            int transpose_flip, bool with2d, void* stream) {
   if (!w || !wp || (KT != 1 && KT != 3) || Cin_layer < 1 || Cout_layer < 1) return HPVG_ERR_ARG;
   const int Cin_k = transpose_flip ? Cout_layer : Cin_layer;
   const int Cout_k = transpose_flip ? Cin_layer : Cout_layer;
   if (conv_is_narrow(Cin_k, Cout_k)) {
-    const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
+    const long total = (long)wpack_floats_impl(Cin_k, Cout_k, KT, with2d);
     hipLaunchKernelGGL(conv_pack_narrow_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
                        Cin_k, Cout_k, KT, hpvg_cdiv(9 * Cout_k, 32), hpvg_cdiv(Cin_k * KT, 2), transpose_flip, total);
     return hpvg_launch_status();
@@ -1429,7 +1503,7 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
   const int CC = conv_cc(Cin_k);
   const int nchunk = hpvg_cdiv(Cin_k, CC);
   const int mbtot = hpvg_cdiv(Cout_k, 32);
-  const long total = (long)hpvg_conv_wpack_floats(Cin_k, Cout_k, KT);
+  const long total = (long)wpack_floats_impl(Cin_k, Cout_k, KT, with2d);
   hipLaunchKernelGGL(conv_pack_kernel, dim3(hpvg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, inv_scale, wp,
                      Cin_k, Cout_k, KT * 9, CC, nchunk, mbtot, transpose_flip, (long)direct_pack_floats(Cin_k, Cout_k, KT), total);
   return hpvg_launch_status();
@@ -1437,7 +1511,15 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
 
 // n <= HPVG_PACK_BATCH_MAX weights of one SQUARE layer shape (C -> C, C > 4) packed in one launch; flip[i] selects the
 // backward-data pack for item i.  Host arrays of device pointers (copied into the kernel arguments).
+static int pack_batch_impl(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, bool with2d, void* stream);
 int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, void* stream) {
+  return pack_batch_impl(n, w, wp, flip, C, KT, true, stream);
+}
+int hpvg_conv_pack_weight_batch_for_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, int B, int T,
+                                        int H, int W, void* stream) {
+  return pack_batch_impl(n, w, wp, flip, C, KT, wants_wino2d(B, C, C, T, H, W, KT), stream);
+}
+static int pack_batch_impl(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, bool with2d, void* stream) {
   if (n < 1 || n > HPVG_PACK_BATCH_MAX || !w || !wp || !flip || C <= 4 || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
   PackBatchArgs a;
   for (int i = 0; i < n; ++i) {
@@ -1447,7 +1529,7 @@ int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* 
   const int CC = conv_cc(C);
   const int nchunk = hpvg_cdiv(C, CC);
   const int mbtot = hpvg_cdiv(C, 32);
-  const long total = (long)hpvg_conv_wpack_floats(C, C, KT);
+  const long total = (long)wpack_floats_impl(C, C, KT, with2d);
   hipLaunchKernelGGL(conv_pack_batch_kernel, dim3(hpvg_cdiv(total, 256), n), dim3(256), 0, (hipStream_t)stream, a, C, KT * 9, CC,
                      nchunk, mbtot, (long)direct_pack_floats(C, C, KT), total);
   return hpvg_launch_status();
@@ -1499,6 +1581,23 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
   const int nchunk = hpvg_cdiv(Cin, CC);
   bool streamk = !sk_off && ws != nullptr && !conv_is_narrow(Cin, Cout);
   bool wino = conv_use_wino(B, Cin, Cout, T, H, W, KT, in_scale != nullptr);
+  if (wino) {
+    const W2Geom q2 = wino2d_geom(B, Cin, Cout, T, H, W, KT);
+    if (conv_use_wino2d(q2, in_scale != nullptr) && !out_mask) {   // (fp32 out-masks: one-axis kernel)
+      Wino2Args w2;
+      w2.x = x; w2.bias = bias; w2.mask_bits = mask_bits; w2.bits_out = bits_out; w2.y = y;
+      w2.wp = wp + direct_pack_floats(Cin, Cout, KT) + wino_pack_floats(Cin, Cout, KT);
+      w2.B = B; w2.Cin = Cin; w2.Cout = Cout; w2.T = T; w2.H = H; w2.W = W;
+      w2.Cq = q2.Cq; w2.R = q2.R; w2.ntq = q2.ntq; w2.tqw = q2.tqw; w2.mbtot = wino2_mb(Cout); w2.gridy = q2.gridy;
+      w2.nsc = q2.nsc; w2.ntl = q2.ntl; w2.PL = W2_PL; w2.out_lrelu = out_lrelu; w2.mbreal = hpvg_cdiv(Cout, 32);
+      // (the mask words are laid out over the layer's real m-tile count)
+      Wino2Args a2 = w2;
+      hipStream_t s2 = (hipStream_t)stream;
+      if (mask_bits) return launch_wino2d_var<VAR_MASK>(a2, s2);
+      if (bits_out) return launch_wino2d_var<VAR_BITS>(a2, s2);
+      return launch_wino2d_var<VAR_PLAIN>(a2, s2);
+    }
+  }
   Plan p = plan_conv(B, Cin, Cout, T, H, W, KT, streamk, wino);
   if (wino && p.L == 0) {  // no Winograd tile fits this shape: the direct kernel takes it
     wino = false;
@@ -1585,9 +1684,14 @@ int hpvg_conv_wino_config(int mode, long min_positions) {
   if (mode >= 0) {
     g_wino_mode = mode > 2 ? 2 : mode;
     g_wino_stg = mode == 3 ? 2 : (mode == 4 ? 1 : 0);   // 3 / 4: every eligible launch AND one staging form forced (tests)
+    // 5: every eligible launch, the two-axis kernel wherever it can run; 3 / 4 / 6: the one-axis kernel only
+    g_wino2d = mode == 5 ? 2 : (mode == 3 || mode == 4 || mode == 6 ? 1 : 0);
   }
   if (min_positions >= 0) g_wino_min_pos = min_positions;
-  return g_wino_mode == 2 && g_wino_stg ? (g_wino_stg == 2 ? 3 : 4) : g_wino_mode;
+  if (g_wino_mode == 2 && g_wino2d == 2) return 5;
+  if (g_wino_mode == 2 && g_wino_stg) return g_wino_stg == 2 ? 3 : 4;
+  if (g_wino_mode == 2 && g_wino2d == 1) return 6;
+  return g_wino_mode;
 }
 
 // Debug/introspection: the tile plan conv_wino_kernel would run this shape with (whether or not the launch picks it):

@@ -456,6 +456,12 @@ int g_wino_mode = -1;          // -1: not configured yet, take the environment's
 long g_wino_min_pos = -1;
 int g_wino_stg = 0;            // staging form of conv_wino_kernel: 0 = by size, 1 = halo'd bands only, 2 = rows-as-in-memory wherever it fits
 inline bool conv_is_wino(int Cin, int Cout) { return wino_env_mode() != 0 && Cin >= 8 && Cout > 32; }
+// the two-axis kernel (conv_wino2d.inl) has its own fragment section behind this one for the 3x3x3 layers; HPVG_WINO2D=0
+// (read once) leaves it out of the packs and of the dispatch
+inline bool conv_is_wino2d(int Cin, int Cout, int KT) {
+  static const bool off = [] { const char* e = getenv("HPVG_WINO2D"); return e && atoi(e) == 0; }();
+  return !off && KT == 3 && conv_is_wino(Cin, Cout);
+}
 inline size_t wino_pack_floats(int Cin, int Cout, int KT) {
   const int nchunk = hpvg_cdiv(Cin, WINO_CC);
   const int mbtot = hpvg_cdiv(Cout, 32);

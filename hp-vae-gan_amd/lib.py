@@ -30,6 +30,10 @@ _SIGS = {
     "hpvg_conv_wpack_floats": [I, I, I],
     "hpvg_conv_pack_weight_f32": [P, P, P, I, I, I, I, P],
     "hpvg_conv_pack_weight_batch_f32": [I, P, P, P, I, I, P],
+    "hpvg_conv_wpack_floats_for": [I, I, I, I, I, I, I],
+    "hpvg_conv_wants_wino2d": [I, I, I, I, I, I, I],
+    "hpvg_conv_pack_weight_for_f32": [P, P, P, I, I, I, I, I, I, I, I, P],
+    "hpvg_conv_pack_weight_batch_for_f32": [I, P, P, P, I, I, I, I, I, I, P],
     "hpvg_conv_fwd_ws_bytes": [I, I, I, I, I, I, I],
     "hpvg_conv_fwd_f32": [P, P, P, P, P, I, P, I, P, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_mask_words": [I, I, I, I, I],
@@ -100,7 +104,7 @@ _SIGS = {
     "hpvg_kl_bern_fwd_f32": [P, P, P, Z, L, P],
     "hpvg_kl_bern_bwd_f32": [P, P, P, L, P],
 }
-_SIZE_FUNCS = {"hpvg_conv_mask_words", "hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
+_SIZE_FUNCS = {"hpvg_conv_wpack_floats_for", "hpvg_conv_mask_words", "hpvg_bn_bwd2_ws_bytes", "hpvg_channel_sum_ws_bytes", "hpvg_conv_fwd_ws_bytes", "hpvg_conv_wpack_floats", "hpvg_conv_bwd_weight_ws_bytes", "hpvg_bn_ws_bytes", "hpvg_reduce_ws_bytes", "hpvg_sn_bwd_ws_bytes"}
 
 
 def header_symbols():

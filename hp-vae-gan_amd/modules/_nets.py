@@ -108,9 +108,10 @@ class SNConv(nn.Module):
         return ops.Conv.apply_bits(x, w, self.bias, act, in_act, mask_by_consumer, in_bits)
 
 
-def sn_weights(convs):
+def sn_weights(convs, x=None):
     """Effective weights of a list of SNConv layers through ONE launch (ops.SpectralNormWeightBatch): the same arithmetic
-    and buffer updates as calling effective_weight() on each, in order."""
+    and buffer updates as calling effective_weight() on each, in order.  x: the activation the chain runs on (its
+    geometry decides which operand forms the packs carry, ops.pack_weight)."""
     out = []
     for i in range(0, len(convs), ops.SN_BATCH_MAX):
         part = convs[i:i + ops.SN_BATCH_MAX]
@@ -119,7 +120,11 @@ def sn_weights(convs):
             args += [m.weight_orig, m.weight_u, m.weight_v]
         out += list(ops.SpectralNormWeightBatch.apply(part[0].training, 1e-12, *args))
     if all(tuple(w.shape[2:]) == (3,) * (w.dim() - 2) for w in out):
-        ops.prepack_weights(out)   # forward and backward-data packs of the equal-shaped layers: one launch
+        geom_k = None
+        if x is not None:
+            B, _, T, H, W = ops.geom(x)
+            geom_k = (B, T, H, W)
+        ops.prepack_weights(out, geom_k=geom_k)   # forward and backward-data packs of the equal-shaped layers: one launch
     return out
 
 
@@ -234,7 +239,7 @@ class FeatureExtractor(nn.Sequential):
         blocks = list(self)
         last = len(blocks) - 1
         bits = None
-        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
+        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks], x))):   # all power iterations in one launch
             x, bits = blk(x, weight=w, in_act=i > 0, mask_by_consumer=(i < last or mask_by_consumer), in_bits=bits, with_bits=True)
         return (x, bits) if mask_by_consumer else x
 
@@ -287,7 +292,7 @@ class WDiscriminator(nn.Module):
         # every activation of the chain has exactly one consumer, the next conv: its LeakyReLU backward rides in that conv's
         # backward-data epilogue (ops.Conv in_act / mask_by_consumer) instead of being a pass of its own
         bits = None
-        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks]))):   # all power iterations in one launch
+        for i, (blk, w) in enumerate(zip(blocks, sn_weights([b.conv for b in blocks], x))):   # all power iterations in one launch
             x, bits = blk(x, weight=w, in_act=i > 0, mask_by_consumer=True, in_bits=bits, with_bits=True)
         return self.tail(x, in_act=True, in_bits=bits)
 

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .lib import call, ptr, stream
+from .lib import call, load, ptr, stream
 
 _ws_cache = {}
 _kernel_timer = None
@@ -102,36 +102,55 @@ def weights_changed():
     _pack_cache.clear()
 
 
-def pack_weight(w, flip):
+def _wants_2d(geom_k, cin_k, cout_k, KT):
+    """Does a launch of this geometry read the pack's two-axis Winograd section?  (lib query; negative results are the
+    common case and decide nothing else)"""
+    if geom_k is None or KT != 3:
+        return None if geom_k is None else False
+    B, T, H, W = geom_k
+    return load().hpvg_conv_wants_wino2d(B, cin_k, cout_k, T, H, W, KT) == 1
+
+
+def pack_weight(w, flip, geom_k=None):
     """Natural [Co][Ci][taps] weight -> MFMA fragment order (forward, or backward-data when flip).
 
     The same weight is packed for several launches between two optimizer steps (rec and rand generator passes; forward,
     backward-data and the double-backward convs of one discriminator evaluation): the packed copy is kept until
     `weights_changed()`, keyed by the weight's storage and validated by its version counter.  The entry holds a
-    detached alias of the weight, so the allocator cannot hand the address to another tensor while the entry lives."""
+    detached alias of the weight, so the allocator cannot hand the address to another tensor while the entry lives.
+    geom_k = (B, T, H, W) of the launch that will read the pack: the two-axis Winograd fragments (the largest section)
+    are then only written when that launch runs the two-axis kernel; without it the pack serves every launch."""
     w = _c(w)
-    key = (w.data_ptr(), bool(flip), tuple(w.shape))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == w._version and hit[1].device == w.device:
-        return hit[2]
     Co, Ci = w.shape[0], w.shape[1]
     KT = _kt(w.shape)
     cin_k, cout_k = (Co, Ci) if flip else (Ci, Co)
-    n = call("hpvg_conv_wpack_floats", cin_k, cout_k, KT)
-    wp = torch.empty(n, dtype=torch.float32, device=w.device)
-    call("hpvg_conv_pack_weight_f32", ptr(w), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, stream())
-    _pack_cache[key] = (w._version, w.detach(), wp)
+    has2d = _wants_2d(geom_k, cin_k, cout_k, KT)
+    key = (w.data_ptr(), bool(flip), tuple(w.shape))
+    hit = _pack_cache.get(key)
+    # (an entry packed with the section serves a launch that does not need it; None = packed without a geometry = all sections)
+    if hit is not None and hit[0] == w._version and hit[1].device == w.device and (hit[3] is None or hit[3] is True or has2d is False):
+        return hit[2]
+    if geom_k is None:
+        n = call("hpvg_conv_wpack_floats", cin_k, cout_k, KT)
+        wp = torch.empty(n, dtype=torch.float32, device=w.device)
+        call("hpvg_conv_pack_weight_f32", ptr(w), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, stream())
+    else:
+        B, T, H, W = geom_k
+        n = call("hpvg_conv_wpack_floats_for", cin_k, cout_k, KT, B, T, H, W)
+        wp = torch.empty(n, dtype=torch.float32, device=w.device)
+        call("hpvg_conv_pack_weight_for_f32", ptr(w), None, ptr(wp), Ci, Co, KT, 1 if flip else 0, B, T, H, W, stream())
+    _pack_cache[key] = (w._version, w.detach(), wp, has2d)
     return wp
 
 
 PACK_BATCH_MAX = 16
 
 
-def prepack_weights(ws, flips=(False, True)):
+def prepack_weights(ws, flips=(False, True), geom_k=None):
     """Pack several weights of one square layer shape (C -> C, C > 4) in ONE launch and leave the results in the pack cache,
     where the convs that follow find them (a discriminator forward packs its six spectral-norm weights twice each - forward
     and backward-data - which used to be a dozen 4.5 us launches in a row).  Weights of other shapes are left to
-    pack_weight."""
+    pack_weight.  geom_k = (B, T, H, W) of the launches that will read them (see pack_weight)."""
     items = []
     for w in ws:
         if w.dim() < 4 or w.shape[0] != w.shape[1] or w.shape[0] <= 4 or not w.is_contiguous():
@@ -146,15 +165,23 @@ def prepack_weights(ws, flips=(False, True)):
     shape = tuple(items[0][0].shape)
     items = [it for it in items if tuple(it[0].shape) == shape][:PACK_BATCH_MAX]
     C, KT = shape[0], _kt(shape)
-    nfl = call("hpvg_conv_wpack_floats", C, C, KT)
+    has2d = _wants_2d(geom_k, C, C, KT)
+    if geom_k is None:
+        nfl = call("hpvg_conv_wpack_floats", C, C, KT)
+    else:
+        nfl = call("hpvg_conv_wpack_floats_for", C, C, KT, *geom_k)
     dev = items[0][0].device
     wps = [torch.empty(nfl, dtype=torch.float32, device=dev) for _ in items]
     m = len(items)
     PA, IA = ctypes.c_void_p * m, ctypes.c_int * m
-    call("hpvg_conv_pack_weight_batch_f32", m, PA(*[ptr(it[0]) for it in items]), PA(*[ptr(t) for t in wps]),
-         IA(*[1 if it[1] else 0 for it in items]), C, KT, stream())
+    if geom_k is None:
+        call("hpvg_conv_pack_weight_batch_f32", m, PA(*[ptr(it[0]) for it in items]), PA(*[ptr(t) for t in wps]),
+             IA(*[1 if it[1] else 0 for it in items]), C, KT, stream())
+    else:
+        call("hpvg_conv_pack_weight_batch_for_f32", m, PA(*[ptr(it[0]) for it in items]), PA(*[ptr(t) for t in wps]),
+             IA(*[1 if it[1] else 0 for it in items]), C, KT, *geom_k, stream())
     for (w, f, key), wp in zip(items, wps):
-        _pack_cache[key] = (w._version, w.detach(), wp)
+        _pack_cache[key] = (w._version, w.detach(), wp, has2d)
 
 
 def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lrelu=False, out_mask=None, mask_bits=None,
@@ -170,7 +197,7 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     cin_k, cout_k = (Co_l, Ci_l) if flip else (Ci_l, Co_l)
     if C != cin_k:
         raise RuntimeError("conv: input has %d channels, weight expects %d" % (C, cin_k))
-    wp = pack_weight(w, flip)
+    wp = pack_weight(w, flip, (B, T, H, W))
     shape = (B, cout_k, T, H, W) if x.dim() == 5 else (B, cout_k, H, W)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     sc = sh = None

@@ -40,6 +40,15 @@ int hpvg_conv_pack_weight_f32(const float* w, const float* inv_scale, float* wp,
  * backward-data pack of item i.  w / wp / flip: host arrays. */
 #define HPVG_PACK_BATCH_MAX 16
 int hpvg_conv_pack_weight_batch_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, void* stream);
+/* Geometry-aware packs.  A pack made by the functions above serves every launch of the layer; the _for forms leave out the
+ * two-axis Winograd fragments (the largest section) unless a launch of the given geometry - kernel view: B, T, H, W of the
+ * conv's input - will read them (hpvg_conv_wants_wino2d), and are valid for launches of that geometry only. */
+size_t hpvg_conv_wpack_floats_for(int Cin, int Cout, int KT, int B, int T, int H, int W);
+int hpvg_conv_wants_wino2d(int B, int Cin, int Cout, int T, int H, int W, int KT); /* host only: 1 / 0 */
+int hpvg_conv_pack_weight_for_f32(const float* w, const float* inv_scale, float* wp, int Cin_layer, int Cout_layer, int KT,
+                                  int transpose_flip, int B, int T, int H, int W, void* stream);
+int hpvg_conv_pack_weight_batch_for_f32(int n, const float* const* w, float* const* wp, const int* flip, int C, int KT, int B, int T,
+                                        int H, int W, void* stream);
 /* ws (optional, may be NULL): scratch of hpvg_conv_fwd_ws_bytes() bytes for the stream-K schedule (512 persistent
  * workgroups share the (tile, channel-chunk) items evenly; tiles cut across workgroups pass through ws as partial sums
  * and are finished in fixed order).  Without it the same kernel runs one workgroup per tile: slower on grids of 1-5
@@ -65,7 +74,9 @@ int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, in
  * the matrix-core work; fp32, ~1e-6 of the output scale away from the direct kernel).  The weight pack carries both forms;
  * which kernel a launch runs is decided per shape.  hpvg_conv_wino_config: mode 0 = direct kernel only, 1 = Winograd from
  * `min_positions` output positions (B*T*H*W) up, 2 = every eligible launch (3 / 4: the same with the kernel's staging form
- * forced - rows as they lie in memory with 16-byte LDS-DMA pieces / halo'd bands with dword pieces; otherwise by size); a
+ * forced - rows as they lie in memory with 16-byte LDS-DMA pieces / halo'd bands with dword pieces; otherwise by size;
+ * 5: every eligible launch, the TWO-axis kernel F(2x2,3x3) - 4/9 of the direct matrix-core work, 3x3x3 only - wherever it
+ * can run, 6: the one-axis kernel only; by default the two-axis kernel takes the largest launches); a
  * negative argument leaves that setting as it is; returns the mode in force (HPVG_ERR_UNSUPPORTED when the process was
  * started with HPVG_WINO=0).  Host only. */
 int hpvg_conv_wino_config(int mode, long min_positions);

@@ -172,6 +172,54 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
 
 
 @pytest.mark.parametrize("B,Cin,Cout,sp", [
+    (1, 64, 64, (2, 4, 6)), (2, 64, 64, (3, 6, 8)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 10, 40, (3, 4, 4)),
+    (2, 64, 64, (5, 36, 130)), (1, 64, 64, (2, 9, 256)), (1, 12, 64, (2, 2, 2)), (2, 64, 64, (3, 57, 104)), (1, 64, 64, (14, 23, 40)),
+])
+def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
+    """conv_wino2d_kernel (F(2x2, 3x3) over H and W, one workgroup per CU, software-pipelined with hand-counted waits;
+    forced wherever it can run: 3x3x3, even W, H*W a multiple of 4) against the oracle and the direct kernel: forward,
+    backward-data, LeakyReLU + 1-bit mask output, masked epilogues; odd H (half a quad row), W = 2, two tiles per quad
+    row, ragged channel counts (sub-chunks past Cin, an odd number of output-channel tiles), several tiles and sub-chunks per
+    workgroup (the pipeline's steady state and its wrap to the next tile)."""
+    from hp_vae_gan_amd import lib as hplib
+    x = _rand(B, Cin, *sp, seed=41)
+    w = _rand(Cout, Cin, 3, 3, 3, seed=42, scale=0.05)
+    b = _rand(Cout, seed=43)
+    gy = _rand(B, Cout, *sp, seed=44)
+    want = O.conv(x, w, b)
+    xr = x.clone().requires_grad_(True)
+    (want_dx,) = torch.autograd.grad(O.conv(xr, w, None), xr, gy)
+    act = O.leaky_relu(want)
+    xd, wd, bd, gyd = x.to(DEV), w.to(DEV), b.to(DEV), gy.to(DEV)
+    res = {}
+    for mode in (5, 0):
+        wino_mode(mode)
+        y = ops.conv_fwd_raw(xd, wd, bd)
+        dx = ops.conv_fwd_raw(gyd, wd, None, flip=True)
+        ya, bits = ops.conv_fwd_raw(xd, wd, bd, out_lrelu=True, want_bits=True)
+        xbits_src, xbits = ops.conv_fwd_raw(gyd, wd, None, flip=True, out_lrelu=True, want_bits=True)
+        dxm_bits = ops.conv_fwd_raw(gyd, wd, None, flip=True, mask_bits=xbits)
+        dxm_f32 = ops.conv_fwd_raw(gyd, wd, None, flip=True, out_mask=xd)
+        res[mode] = dict(y=y, dx=dx, ya=ya, bits=bits, dxm_bits=dxm_bits, dxm_f32=dxm_f32, xbits_src=xbits_src)
+    for mode, r in res.items():
+        tag = "wino2d." if mode == 5 else "direct."
+        assert_close(r["y"], want, RTOL, tag + "y")
+        assert_close(r["dx"], want_dx, RTOL, tag + "dx")
+        assert_close(r["ya"], act, RTOL, tag + "lrelu")
+        assert_close(r["dxm_f32"], want_dx * torch.where(x > 0, 1.0, 0.2), RTOL, tag + "dx.mask_f32")
+        m = torch.where(r["xbits_src"] > 0, 1.0, 0.2)
+        assert_close(r["dxm_bits"], r["dx"] * m, 1e-6, tag + "dx.mask_bits")
+    for k in ("y", "dx", "ya", "dxm_f32"):
+        assert_close(res[5][k], res[0][k], 3e-5, "wino2d-vs-direct." + k)
+    mt = (Cout + 31) // 32
+    bw = res[5]["bits"].view(B, -1, mt).cpu()
+    yw = res[5]["ya"].reshape(B, Cout, -1).cpu()
+    for c in (0, Cout // 2, Cout - 1):
+        got = (bw[:, :, c // 32] >> (c % 32)) & 1
+        assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
+
+
+@pytest.mark.parametrize("B,Cin,Cout,sp", [
     (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 16, 24, (3, 4, 7)),
     (1, 8, 8, (1, 1, 1)), (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (1, 5, 70, (2, 3, 300)),
     (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),

@@ -27,7 +27,9 @@ def test_library_loads_and_exports_header_symbols():
 
 def test_size_queries_and_plans_run_without_gpu():
     # wide layers carry the Winograd U fragments (36 tap-points per chunk + 4 of tail padding) behind the direct pack
-    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 3) == (8 * 27 + 2) * 2 * 64 * 4 + (8 * 36 + 4) * 2 * 64 * 4
+    # ... and the 3x3x3 ones the two-axis U fragments behind those ([16 sub-chunks][3 dt][2 channel pairs][4 rows][2 m-tiles][64][4])
+    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 3) == (8 * 27 + 2) * 2 * 64 * 4 + (8 * 36 + 4) * 2 * 64 * 4 + 16 * 3 * 2 * 4 * 2 * 64 * 4
+    assert hplib.call("hpvg_conv_wpack_floats", 64, 64, 1) == (8 * 9 + 2) * 2 * 64 * 4 + (8 * 12 + 4) * 2 * 64 * 4
     assert hplib.call("hpvg_conv_wpack_floats", 64, 32, 3) == (8 * 27 + 2) * 1 * 64 * 4     # Cout <= 32: direct kernel only
     assert hplib.call("hpvg_conv_wpack_floats", 3, 64, 3) == (1 * 27 + 2) * 2 * 64 * 2
     out = (ctypes.c_int * 10)()

@@ -34,9 +34,15 @@ for st in stages:
     b = torch.randn(64, device=dev)
     flops = 2.0 * B * 64 * 64 * (27 if dims == 3 else 9) * x[0, 0].numel()
     row = {}
-    for mode in (0, 2):
+    for mode in (0, 2) if dims == 2 else (0, 6, 5):   # direct | one-axis Winograd | two-axis where it can run (else one-axis)
         lib.hpvg_conv_wino_config(mode, -1)
         row[mode] = (bench(lambda: ops.conv_fwd_raw(x, w, b)), bench(lambda: ops.conv_fwd_raw(x, w, None, flip=True)))
+    if dims == 3:
+        lib.hpvg_conv_wino_config(0, -1); yd = ops.conv_fwd_raw(x, w, b)
+        lib.hpvg_conv_wino_config(5, -1); y5 = ops.conv_fwd_raw(x, w, b)
+        row[2] = row[6]
+        print("stage %d  two-axis fwd %.4f bwd %.4f ms  x%.3f over one-axis  %.1f TFLOP/s (algorithmic)  rel diff vs direct %.2e"
+              % (st, row[5][0], row[5][1], row[6][0] / row[5][0], flops / row[5][0] / 1e9, float((y5 - yd).abs().max() / yd.abs().max())), flush=True)
     y0 = None
     lib.hpvg_conv_wino_config(0, -1); y0 = ops.conv_fwd_raw(x, w, b)
     lib.hpvg_conv_wino_config(2, -1); y2 = ops.conv_fwd_raw(x, w, b)
