@@ -1305,7 +1305,7 @@ int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
     attr_set = true;
   }
   const int S = a.ntl < HPVG_NUM_CU ? a.ntl : HPVG_NUM_CU;
-  hipLaunchKernelGGL(kern, dim3(S), dim3(256), (size_t)2 * 12 * W2_PL * sizeof(float), s, a);
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), (size_t)3 * 12 * W2_PL * sizeof(float), s, a);   // three input buffers
   return hpvg_launch_status();
 }
 

@@ -94,11 +94,7 @@ __device__ __forceinline__ void w2_dma16(const char* src, unsigned lds_addr) {
 }
 // one U fragment (16 bytes per lane): scalar base + 32-bit lane offset; the result is NOT ready when the statement ends -
 // every use goes through W2_WAIT_A first
-__device__ __forceinline__ void w2_load_a(f32x4& dst, unsigned voff, const char* base_) {
-  const unsigned long long bb = (unsigned long long)base_;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32));
-  const unsigned long long base = (unsigned long long)lo | ((unsigned long long)hi << 32);
+__device__ __forceinline__ void w2_load_a(f32x4& dst, unsigned voff, const char* base) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
 #define W2_WAIT_A(N, S)                                                                               \
@@ -172,9 +168,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     return q;
   };
 
-  int c_yb = 0, c_b = 0, c_t = 0, c_h = 0, c_w = 0, c_base = 0;
+  // compute state of a tile: where this lane's quad is (epilogue) and how it reads its patches (K loop)
+  struct ReadT { int base; float f0, f3; };
+  int c_yb = 0, c_b = 0, c_t = 0, c_h = 0, c_w = 0;
   bool c_vq = false;
-  float f0 = 1.f, f3 = 1.f;
+  auto read_setup = [&](int tile) __attribute__((always_inline)) -> ReadT {
+    ReadT q;
+    int b, t, Rr, tw, yb;
+    decode(tile, b, t, Rr, tw, yb);
+    const int qi = nw * 32 + l31;
+    const int w = 2 * (tw * a.tqw + qi);
+    const int lo = (2 * Rr - 1) * W + 2 * tw * a.tqw - 1;
+    const int sh = lo - span_lo4(Rr, tw) + 1;                    // 2 or 4: image offset of the tile's first input
+    q.base = half * 3 * PL + sh + 2 * qi;                        // + (2 cp * 3 + dt) * PL + r * W + c
+    q.f0 = w == 0 ? 0.f : 1.f;
+    q.f3 = w + 2 >= W ? 0.f : 1.f;
+    return q;
+  };
   auto cmp_setup = [&](int tile) __attribute__((always_inline)) {
     int Rr, tw;
     decode(tile, c_b, c_t, Rr, tw, c_yb);
@@ -183,11 +193,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     c_vq = qi < a.tqw && cq < a.Cq;
     c_h = 2 * Rr;
     c_w = 2 * cq;
-    const int lo = (2 * Rr - 1) * W + 2 * tw * a.tqw - 1;
-    const int sh = lo - span_lo4(Rr, tw) + 1;                    // 2 or 4: image offset of the tile's first input
-    c_base = half * 3 * PL + sh + 2 * qi;                        // + (2 cp * 3 + dt) * PL + r * W + c
-    f0 = c_w == 0 ? 0.f : 1.f;
-    f3 = c_w + 2 >= W ? 0.f : 1.f;
   };
   // first plane (channel 4 sc, time t - 1) of a sub-chunk of a staged tile; the 12 planes follow at (cc * T + dt) * HWb
   const long THWb = (long)a.T * HWb;
@@ -195,9 +200,39 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     return reinterpret_cast<const char*>(a.x) + (((long)q.b * a.Cin + (long)sc * 4) * a.T + (q.t - 1)) * HWb;
   };
 
+  // ---- three LDS buffers: item i computes from buffer i % 3 while item i + 1 lands in the next one; the barrier that
+  // publishes it sits BEFORE the last step of item i, whose slots read and transform the first patch of item i + 1, so an
+  // item starts with its first MFMA (the third buffer keeps the DMA of item i + 2 off a buffer some wave may still read).
+#define W2_LOAD_RAW(XL, STEP)                                                                   \
+  {                                                                                             \
+    const int so_ = (((STEP) & 1) * 6 + ((STEP) >> 1)) * (PL / 2);                              \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                          \
+      raw[r_][0] = (XL)[so_ + r_ * (W / 2)];                                                    \
+      raw[r_][1] = (XL)[so_ + r_ * (W / 2) + 1];                                                \
+    }                                                                                           \
+  }
+// input transform V = B^T d B of the patch in `raw`: the row pass of column C, then the column pass of row I (with the image
+// border factors folded in)
+#define W2_ROWPASS(C)                                                                           \
+  {                                                                                             \
+    const float d0_ = raw[0][(C) >> 1][(C) & 1], d1_ = raw[1][(C) >> 1][(C) & 1];               \
+    const float d2_ = raw[2][(C) >> 1][(C) & 1], d3_ = raw[3][(C) >> 1][(C) & 1];               \
+    tn[0][C] = d0_ - d2_; tn[1][C] = d1_ + d2_; tn[2][C] = d2_ - d1_; tn[3][C] = d1_ - d3_;     \
+  }
+#define W2_COLPASS(I, OUT, F0, F3)                                                              \
+  {                                                                                             \
+    OUT[(I) * 4 + 0] = __builtin_fmaf(F0, tn[I][0], -tn[I][2]);                                 \
+    OUT[(I) * 4 + 1] = tn[I][1] + tn[I][2];                                                     \
+    OUT[(I) * 4 + 2] = tn[I][2] - tn[I][1];                                                     \
+    OUT[(I) * 4 + 3] = __builtin_fmaf(-(F3), tn[I][3], tn[I][1]);                               \
+  }
+  f32x2a raw[4][2];
+  float vc[16], vn[16], tn[4][4];
+
   // ---- prologue: first item of the first tile (nothing to overlap with)
   int tile = g;
   StageT st_cur = stage_setup(tile);
+  ReadT rd_cur = read_setup(tile);
   {
     const char* ab = reinterpret_cast<const char*>(a.wp) + ((long)((tile % a.gridy) * 2 + mw)) * 1024;
 #pragma unroll
@@ -216,18 +251,32 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
+  {
+    const f32x2a* xl0 = reinterpret_cast<const f32x2a*>(xs + rd_cur.base);
+    W2_LOAD_RAW(xl0, 0)
+    W2_ROWPASS(0) W2_ROWPASS(1) W2_ROWPASS(2) W2_ROWPASS(3)
+    W2_COLPASS(0, vc, rd_cur.f0, rd_cur.f3) W2_COLPASS(1, vc, rd_cur.f0, rd_cur.f3)
+    W2_COLPASS(2, vc, rd_cur.f0, rd_cur.f3) W2_COLPASS(3, vc, rd_cur.f0, rd_cur.f3)
+  }
 
   int bufsel = 0;
+  const long scstride = 4 * THWb;          // bytes between the first planes of two sub-chunks
+  const long ascstride = 24 * afrag;       // bytes between the U fragments of two sub-chunks
 #pragma unroll 1
   for (int k = 0; k < nmy; ++k) {
     const bool last_tile = k + 1 == nmy;
     const int ntile = last_tile ? tile : tile + S;
-    // what the LAST sub-chunk of this tile stages: sub-chunk 0 of the next tile (the workgroup's last tile stages its own
-    // sub-chunk 0 again - never used, but the instruction stream, and with it every wait count, is the same for all items)
+    // what the LAST sub-chunk of this tile stages and prefetches: sub-chunk 0 of the next tile (the workgroup's last tile
+    // takes its own sub-chunk 0 again - never used, but the instruction stream, and with it every wait count, is the same
+    // for all items)
     const StageT st_nxt = last_tile ? st_cur : stage_setup(ntile);
+    const ReadT rd_nxt = last_tile ? rd_cur : read_setup(ntile);
     cmp_setup(tile);
     const char* abase_cur = reinterpret_cast<const char*>(a.wp) + ((long)((tile % a.gridy) * 2 + mw)) * 1024;
     const char* abase_nxt = reinterpret_cast<const char*>(a.wp) + ((long)((ntile % a.gridy) * 2 + mw)) * 1024;
+    const char* lane0_cur = plane0(st_cur, 0) + st_cur.voff;
+    const char* lane0_nxt = plane0(st_nxt, 0) + st_nxt.voff;
+    const float f0 = rd_cur.f0, f3 = rd_cur.f3;
 
     f32x16 acc[16];
 #pragma unroll
@@ -239,82 +288,78 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     for (int sc = 0; sc < nsc; ++sc) {
       const bool wrap = sc + 1 == nsc;
       const int nsc_i = wrap ? 0 : sc + 1;
-      const int cb = bufsel, nb = bufsel ^ 1;
-      bufsel ^= 1;
-      // the item after this one
-      const int n_t = wrap ? st_nxt.t : st_cur.t;
-      const unsigned n_voff = wrap ? st_nxt.voff : st_cur.voff;
-      const bool n_ok = wrap ? st_nxt.ok : st_cur.ok;
-      const char* np0 = plane0(wrap ? st_nxt : st_cur, nsc_i);
+      const int cb = bufsel, nb = bufsel == 2 ? 0 : bufsel + 1;
+      bufsel = nb;
+      // the item after this one: its planes (validity per channel / time tap, scalar; this lane's address in a valid plane)
       const int nch0 = nsc_i * 4;
-      const char* anext = (wrap ? abase_nxt : abase_cur) + (long)nsc_i * 24 * afrag;
+      const char* lane_real = wrap ? lane0_nxt : lane0_cur + (long)nsc_i * scstride;
+      const bool n_ok = wrap ? st_nxt.ok : st_cur.ok;
+      const int n_t = wrap ? st_nxt.t : st_cur.t;
+      const char* anext = (wrap ? abase_nxt : abase_cur) + (long)nsc_i * ascstride;
       const unsigned ldsn = lds0 + (unsigned)((nb * BUFF + 1) * 4 + wave * 1024);
-      // plane pl = cc * 3 + dt of the next item into buffer nb
-#define W2_STAGE(PLN)                                                                                             \
+      const float nf0 = wrap ? rd_nxt.f0 : f0, nf3 = wrap ? rd_nxt.f3 : f3;
+      const f32x2a* xl = reinterpret_cast<const f32x2a*>(xs + cb * BUFF + rd_cur.base);   // 8-byte units (base, PL, W are even)
+      const f32x2a* xln = reinterpret_cast<const f32x2a*>(xs + nb * BUFF + (wrap ? rd_nxt.base : rd_cur.base));
+      // plane pl = cc * 3 + dt of the next item into buffer nb: the source address one slot ahead of the piece itself (an
+      // LDS-DMA instruction occupies the issue port for ~60 cycles: its slot holds nothing else that can be moved)
+      const char* stg_src = zero_ptr;
+#define W2_STAGE_ADDR(PLN)                                                                                        \
   {                                                                                                               \
     const int cc_ = (PLN) / 3, dt_ = (PLN) - 3 * cc_;                                                             \
-    const int tt_ = n_t + dt_ - 1;                                                                                \
-    const bool pok_ = nch0 + cc_ < a.Cin && tt_ >= 0 && tt_ < a.T;                                                \
-    const char* src_ = (pok_ && n_ok) ? np0 + ((long)cc_ * THWb + (long)dt_ * HWb) + n_voff : zero_ptr;           \
-    w2_dma16(src_, ldsn + (unsigned)((PLN) * PL * 4));                                                            \
+    const bool pok_ = nch0 + cc_ < a.Cin && n_t + dt_ - 1 >= 0 && n_t + dt_ - 1 < a.T;                            \
+    stg_src = (pok_ && n_ok) ? lane_real + ((long)cc_ * THWb + (long)dt_ * HWb) : zero_ptr;                       \
   }
-
-      const f32x2a* xl = reinterpret_cast<const f32x2a*>(xs + cb * BUFF + c_base);   // 8-byte units (c_base, PL, W are even)
-      f32x2a raw[2][4][2];
-#define W2_LOAD_RAW(SET, STEP)                                                                  \
-  {                                                                                             \
-    const int so_ = (((STEP) & 1) * 6 + ((STEP) >> 1)) * (PL / 2);                              \
-    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                          \
-      raw[SET][r_][0] = xl[so_ + r_ * (W / 2)];                                                 \
-      raw[SET][r_][1] = xl[so_ + r_ * (W / 2) + 1];                                             \
-    }                                                                                           \
-  }
-      W2_LOAD_RAW(0, 0)
+#define W2_STAGE(PLN) w2_dma16(stg_src, ldsn + (unsigned)((PLN) * PL * 4));
       // ---- wait counts (vector-memory ops return in order; a wait for "at most N outstanding" retires everything but the N
-      // youngest).  Per item this wave issues, in program order: step s < 3: four DMA pieces (between the MFMAs), then the
-      // four U loads of slot s for the NEXT item; steps 3-5: the four U loads only.  The U loads of slot s are used six steps
-      // later; issued after them by then: 5 x 4 U loads and every DMA piece of one item except the four of step s itself
-      // (those precede the slot's loads) -> N = 20 + 12 - 4 = 28 for s < 3, 20 + 12 = 32 for s >= 3.  Extra younger ops the
-      // count does not know (the epilogue's stores, the compiler's own loads) only make a wait stricter, never too weak.
-      // Item end: the next buffer is complete when at most the 16 U loads of slots 2-5 (issued after the last piece) are out.
+      // youngest).  Per item this wave issues, in program order: step s < 3: four DMA pieces (slots 1, 5, 9, 13), then the
+      // four U loads of ring slot s for the NEXT item (slots 12-15; the piece of slot 13 follows the first of them: counted
+      // as if it preceded all four - a wait that is one op too strict at worst); steps 3-5: the four U loads only.  The U loads
+      // of slot s are used six steps later; issued after them by then: 5 x 4 U loads and every DMA piece of one item except the
+      // four of step s itself -> N = 20 + 12 - 4 = 28 for s < 3, 20 + 12 = 32 for s >= 3.  Extra younger ops the count does not
+      // know (the epilogue's stores, the compiler's own loads) only make a wait stricter, never too weak.
+      // Before step 5 the next buffer must be complete: younger than the last piece (step 2, slot 13) are the U loads of slots
+      // 14, 15 of step 2 and the eight of steps 3, 4 -> vmcnt(10), then the barrier.
       // The kernel ends with vmcnt(0): the last item's unused pieces must have landed before the LDS is given back.
+      // ---- one step = 16 slots: ONE MFMA and a small unit of other work that fits its 64-cycle shadow (one wave per SIMD:
+      // nothing else hides them): slot 0 the LDS reads of the next step's patch, 4-7 its row pass, 8-11 its column pass,
+      // 12-15 the U loads of this ring slot for the next item, 1 / 5 / 9 / 13 a DMA piece (steps 0-2).  Step 5 does that for
+      // step 0 of the NEXT item (other buffer, the next tile's border factors at a tile wrap).
+#define W2_SLOT(STEP, K)                                                                                           \
+  {                                                                                                                \
+    acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[STEP][(K) >> 2][(K) & 3], vc[K], acc[K], 0, 0, 0);            \
+    if ((K) == 0 && (STEP) < 5) W2_LOAD_RAW(xl, (STEP) + 1)                                                        \
+    if ((K) == 0 && (STEP) == 5) W2_LOAD_RAW(xln, 0)                                                               \
+    if ((K) >= 4 && (K) < 8) W2_ROWPASS((K) & 3)                                                                   \
+    if ((K) >= 8 && (K) < 12 && (STEP) < 5) W2_COLPASS((K) & 3, vn, f0, f3)                                        \
+    if ((K) >= 8 && (K) < 12 && (STEP) == 5) W2_COLPASS((K) & 3, vn, nf0, nf3)                                     \
+    if (((K) & 3) == 0 && (STEP) < 3) W2_STAGE_ADDR((STEP) * 4 + ((K) >> 2))                                       \
+    if (((K) & 3) == 1 && (STEP) < 3) W2_ABL_STAGE((STEP) * 4 + ((K) >> 2))                                        \
+    if ((K) >= 12) W2_ABL_LOADA(av[STEP][(K) & 3], aoff, anext + (long)((STEP) * 4 + ((K) & 3)) * afrag);          \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  }
 #define W2_STEP(STEP, NWAIT)                                                                                       \
   {                                                                                                                \
-    if ((STEP) < 5) W2_LOAD_RAW(((STEP) + 1) & 1, (STEP) + 1)                                                      \
     W2_WAIT_A(NWAIT, STEP);                                                                                        \
-    float t_[4][4];                                                                                                \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                             \
-      const float d0_ = raw[(STEP) & 1][0][c_ >> 1][c_ & 1], d1_ = raw[(STEP) & 1][1][c_ >> 1][c_ & 1];            \
-      const float d2_ = raw[(STEP) & 1][2][c_ >> 1][c_ & 1], d3_ = raw[(STEP) & 1][3][c_ >> 1][c_ & 1];            \
-      t_[0][c_] = d0_ - d2_; t_[1][c_] = d1_ + d2_; t_[2][c_] = d2_ - d1_; t_[3][c_] = d1_ - d3_;                  \
-    }                                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                             \
-      const float v0_ = __builtin_fmaf(f0, t_[i_][0], -t_[i_][2]);                                                 \
-      const float v1_ = t_[i_][1] + t_[i_][2];                                                                     \
-      const float v2_ = t_[i_][2] - t_[i_][1];                                                                     \
-      const float v3_ = __builtin_fmaf(-f3, t_[i_][3], t_[i_][1]);                                                 \
-      acc[i_ * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[STEP][i_][0], v0_, acc[i_ * 4 + 0], 0, 0, 0);      \
-      acc[i_ * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[STEP][i_][1], v1_, acc[i_ * 4 + 1], 0, 0, 0);      \
-      acc[i_ * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[STEP][i_][2], v2_, acc[i_ * 4 + 2], 0, 0, 0);      \
-      acc[i_ * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[STEP][i_][3], v3_, acc[i_ * 4 + 3], 0, 0, 0);      \
-      if ((STEP) < 3) W2_ABL_STAGE((STEP) * 4 + i_)                                                                \
-    }                                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                               \
-      W2_ABL_LOADA(av[STEP][i_], aoff, anext + (long)((STEP) * 4 + i_) * afrag);                                   \
+    W2_SLOT(STEP, 0) W2_SLOT(STEP, 1) W2_SLOT(STEP, 2) W2_SLOT(STEP, 3)                                            \
+    W2_SLOT(STEP, 4) W2_SLOT(STEP, 5) W2_SLOT(STEP, 6) W2_SLOT(STEP, 7)                                            \
+    W2_SLOT(STEP, 8) W2_SLOT(STEP, 9) W2_SLOT(STEP, 10) W2_SLOT(STEP, 11)                                          \
+    W2_SLOT(STEP, 12) W2_SLOT(STEP, 13) W2_SLOT(STEP, 14) W2_SLOT(STEP, 15)                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) vc[q_] = vn[q_];                                             \
   }
       W2_STEP(0, 28)
       W2_STEP(1, 28)
       W2_STEP(2, 28)
       W2_STEP(3, 32)
       W2_STEP(4, 32)
+#ifndef HPVG_ABL2_NOBAR
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // buffer nb is complete for every wave (and everybody is past the item before)
+#endif
       W2_STEP(5, 32)
 #undef W2_STEP
-#undef W2_LOAD_RAW
+#undef W2_SLOT
 #undef W2_STAGE
-#ifndef HPVG_ABL2_NOBAR
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");   // every wave is done with buffer cb, and buffer nb is complete
-#endif
+#undef W2_STAGE_ADDR
     }
 
     {
@@ -396,8 +441,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
       }
     }
     st_cur = st_nxt;
+    rd_cur = rd_nxt;
     tile = ntile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#undef W2_COLPASS
+#undef W2_ROWPASS
+#undef W2_LOAD_RAW
 #undef W2_WAIT_A
