@@ -37,11 +37,18 @@ if json_out:
     import json
     rows = {k: 2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024 for k in set(f) | set(w)}
     # (the Winograd kernel when the library runs the shape on it - conv_wino_kernel<3, 2, 0> - else the direct one)
-    wino = [k for k in rows if "conv_wino_kernel<" in k[0] and k[0].rstrip(">").endswith(" 0")]
-    main = max(wino or [k for k in rows if "conv_mfma_kernel<8" in k[0] and k[0].rstrip(">").endswith(" 0")], key=lambda k: rows[k])
-    fix = max((k for k in rows if ("conv_wino_fixup_kernel" if wino else "conv_fixup_kernel") in k[0]), key=lambda k: rows[k])
-    ent = {"shape": shape, "bytes": round(rows[main] + rows[fix]), "source": cite,
-           "rows": {"%s grid %s" % main: round(rows[main]), "%s grid %s" % fix: round(rows[fix])}}
+    # (the kernel the library runs the shape on: two-axis Winograd conv_wino2d_kernel<0> - whole tiles, no fix-up launch -,
+    # else one-axis conv_wino_kernel<3, 2, 0, *>, else the direct one)
+    w2 = [k for k in rows if "conv_wino2d_kernel<0>" in k[0]]
+    wino = [k for k in rows if "conv_wino_kernel<" in k[0] and ", 0, " in k[0]]
+    if w2:
+        main = max(w2, key=lambda k: rows[k])
+        ent = {"shape": shape, "bytes": round(rows[main]), "source": cite, "rows": {"%s grid %s" % main: round(rows[main])}}
+    else:
+        main = max(wino or [k for k in rows if "conv_mfma_kernel<8" in k[0] and k[0].rstrip(">").endswith(" 0")], key=lambda k: rows[k])
+        fix = max((k for k in rows if ("conv_wino_fixup_kernel" if wino else "conv_fixup_kernel") in k[0]), key=lambda k: rows[k])
+        ent = {"shape": shape, "bytes": round(rows[main] + rows[fix]), "source": cite,
+               "rows": {"%s grid %s" % main: round(rows[main]), "%s grid %s" % fix: round(rows[fix])}}
     json.dump({"note": "HBM bytes per launch of bench.py's roofline kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                        "(gfx950: FETCH_SIZE x 2; tools/pmc_summary.py); bench.py reports `traffic` from here", "entries": [ent]},
               open(json_out, "w"), indent=1)
