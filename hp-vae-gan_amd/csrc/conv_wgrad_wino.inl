@@ -18,6 +18,14 @@
 
 typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
 
+// development ablation (timing only, results wrong): -DHPVG_ABLW_NODMA stages nothing from inside the K loop
+#ifdef HPVG_ABLW_NODMA
+#define WGW_ABL_DY {}
+#define WGW_ABL_XX { if (cnext < 64) ++cnext; }
+#else
+#define WGW_ABL_DY { if (cnext < 64) dma_dy(cnext); }
+#define WGW_ABL_XX { if (cnext < 64) { dma_xx(cnext); ++cnext; } }
+#endif
 template <int KT, int NJD, int NJX>
 __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -111,7 +119,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     dma_d = buf + wave * 64;
     dma_x = buf + 64 * DS + wave * 64;
   };
-  auto dma_channel = [&](int c) {
+  // (the two halves of a channel are issued behind DIFFERENT MFMAs of the K loop: an LDS-DMA instruction holds the issue port
+  // for about one MFMA's duration, and with one wave per SIMD whatever does not fit an MFMA's shadow stalls the matrix pipe)
+  auto dma_dy = [&](int c) {
     if (c < no) {
 #pragma unroll
       for (int j = 0; j < NJD; ++j) {
@@ -119,6 +129,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
         dptr[j] += dstr[j];
       }
     }
+    dma_d += DS;
+  };
+  auto dma_xx = [&](int c) {
     if (c < nc) {
 #pragma unroll
       for (int j = 0; j < NJX; ++j) {
@@ -126,8 +139,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
         xptr[j] += xstr[j];
       }
     }
-    dma_d += DS;
     dma_x += XS;
+  };
+  auto dma_channel = [&](int c) {
+    dma_dy(c);
+    dma_xx(c);
   };
 
   int tile = slot;
@@ -167,7 +183,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       B1[dh] = *reinterpret_cast<const wf32x2a*>(xl + q0_ + dh * RS + 2);                \
     }                                                                                    \
   }
-// 12 MFMAs with three channels of DMA staging slotted in between (the rate per position of conv_wgrad_kernel)
+// 12 MFMAs with three channels of DMA staging between them (the rate per position of conv_wgrad_kernel): a channel's dY
+// piece behind the second MFMA of a group, its X piece behind the fourth
 #define WW_MMA(A, B0, B1)                                                                                          \
   {                                                                                                                \
     const float y0_ = A[0], y1_ = A[1];                                                                            \
@@ -175,10 +192,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                                             \
       const float d0_ = B0[dh][0], d1_ = B0[dh][1], d2_ = B1[dh][0], d3_ = B1[dh][1];                              \
       acc[dh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0_, d0_ - d2_, acc[dh * 4 + 0], 0, 0, 0);            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
       acc[dh * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ys_, d1_ + d2_, acc[dh * 4 + 1], 0, 0, 0);            \
+      WGW_ABL_DY                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
       acc[dh * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(yd_, d2_ - d1_, acc[dh * 4 + 2], 0, 0, 0);            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
       acc[dh * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yn_, d1_ - d3_, acc[dh * 4 + 3], 0, 0, 0);            \
-      if (cnext < 64) { dma_channel(cnext); ++cnext; }                                                             \
+      WGW_ABL_XX                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
     }                                                                                                              \
   }
       int st = 0;
