@@ -1276,24 +1276,37 @@ inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT)
   if (!conv_is_wino2d(Cin, Cout, KT) || (W & 1) || (((long)H * W) & 3) || W < 2) return q;
   q.Cq = W / 2;
   q.R = hpvg_cdiv(H, 2);
-  q.ntq = hpvg_cdiv(q.Cq, 64);
-  q.tqw = hpvg_cdiv(q.Cq, q.ntq);
-  if (3 * W + 2 * q.tqw + 8 > 1024) return q;          // the staged span of a tile: one 16-byte group per lane
+  const int nq = q.R * q.Cq;
+  q.ntq = hpvg_cdiv(nq, 64);                            // tiles per plane: 64 consecutive quads each
+  q.tqw = 64;
+  // the staged span of every tile (first input of its first quad, rounded down to a multiple of 4, to the last input of its
+  // last quad): one 16-byte group per lane
+  for (int tp = 0; tp < q.ntq; ++tp) {
+    const int Q0 = tp * 64, R0 = Q0 / q.Cq, c0 = Q0 - R0 * q.Cq;
+    int Ql = Q0 + 63;
+    if (Ql > nq - 1) Ql = nq - 1;
+    const int R1 = Ql / q.Cq, c1 = Ql - R1 * q.Cq;
+    const int lo = (2 * R0 - 1) * W + 2 * c0 - 1;
+    const int lo4 = lo >= 0 ? (lo & ~3) : -((3 - lo) & ~3);
+    const int hi = (2 * R1 + 2) * W + 2 * c1 + 3;
+    if (hi - lo4 > 1024) return q;
+  }
   q.gridy = hpvg_cdiv(hpvg_cdiv(Cout, 32), 2);
   q.nsc = hpvg_cdiv(Cin, 4);
-  const long ntl = (long)B * T * q.R * q.ntq * q.gridy;
+  const long ntl = (long)B * T * q.ntq * q.gridy;
   if (ntl > 0x7fffffffL) return q;
   q.ntl = (int)ntl;
   q.ok = true;
   return q;
 }
 // Taken by size where it was measured to win (tools/perf_wino.py, profiles/r02_perf_wino2d.txt): whole tiles, one
-// workgroup per CU and no stream-K need >= 8 rounds of tiles, and a tile must fill most of its 64 quads - stage 9 (64 of 64,
-// 14.6 rounds): 1.14 vs 1.31 ms for the one-axis kernel + fix-up; stage 8 (51 of 64 quads, 5 rounds): 0.53 vs 0.46.
-constexpr long W2_MIN_TILES = 8L * HPVG_NUM_CU;
+// workgroup per CU and no stream-K want a few rounds of tiles - stage 9 (14.6 rounds at B = 2): 1.05 vs 1.31 ms for the
+// one-axis kernel + fix-up; stage 8 (5 rounds): 0.354 vs 0.458 (0.53 while its tiles were cut per quad row and filled 51
+// of their 64 quads).
+constexpr long W2_MIN_TILES = 4L * HPVG_NUM_CU;
 inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
-  return g_wino2d == 2 || (q.ntl >= W2_MIN_TILES && q.tqw >= 56);
+  return g_wino2d == 2 || q.ntl >= W2_MIN_TILES;
 }
 template <int VAR>
 int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {

@@ -11,8 +11,9 @@
 // Sixteen points x 16 registers = 256 accumulator registers per wave for ONE 32-quad block, so this kernel runs ONE
 // workgroup per CU (256 AGPRs + 256 VGPRs per lane) and hides its own memory latency instead of relying on a co-resident
 // workgroup:
-//  * tile = 64 output channels x 64 quads of one quad-row (2 rows x 128 columns); waves 0/2 hold channel tile 0, waves
-//    1/3 tile 1; waves 0-1 the first 32 quads, waves 2-3 the second;
+//  * tile = 64 output channels x 64 consecutive quads of the plane's row-major quad index (2 rows x 128 columns when a
+//    row is a multiple of 64 quads; otherwise a tile may run over into the next quad row); waves 0/2 hold channel tile 0,
+//    waves 1/3 tile 1; waves 0-1 the first 32 quads, waves 2-3 the second;
 //  * the K loop runs over ITEMS = (tile, 4-channel sub-chunk): 6 steps (dt, channel pair) of 16 MFMAs.  The input planes
 //    of item i+1 (12 planes, rows as they lie in memory: one 16-byte LDS-DMA piece of 256 lanes per plane, source address
 //    per lane = inside the plane or a zero word - no masks, no zero-fill pass, a constant number of pieces) land in the
@@ -22,7 +23,8 @@
 //    order): the compiler would otherwise drain the LDS-DMA queue in front of every use of a loaded U fragment
 //    (cdna_hip_programming.md, "Pipelining across barriers").  Count rules are next to WAIT_A below.
 // Eligibility (conv_use_wino2d): 3x3x3, Cin >= 8, Cout > 32, even W, H*W a multiple of 4 (16-byte groups never straddle
-// the end of a plane), a staged span of at most 256 groups (W <= ~290), enough tiles to fill the chip several times.
+// the end of a plane), a staged span of at most 256 groups (W <= 298; <= ~210 when tiles wrap over quad rows), enough
+// tiles to fill the chip several times.
 
 struct Wino2Args {
   const float* x;
@@ -32,7 +34,7 @@ struct Wino2Args {
   unsigned* bits_out;
   float* y;
   int B, Cin, Cout, T, H, W;
-  int Cq, R, ntq, tqw;    // quads per row, quad rows, tiles per quad row, quads per tile
+  int Cq, R, ntq, tqw;    // quads per row, quad rows, tiles per plane (64 consecutive quads each), unused
   int mbtot, gridy, nsc, ntl, PL, out_lrelu;
   int mbreal;             // m-tiles of the layer (the 1-bit mask words' layout); mbtot is rounded up to an even count
 };
@@ -139,28 +141,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
   const unsigned aoff = (unsigned)(lane * 16);
   f32x4 av[6][4];                                    // ring: slot = step of the sub-chunk
 
-  auto decode = [&](int tile, int& b, int& t, int& Rr, int& tw, int& yb) __attribute__((always_inline)) {
+  // a tile = 64 consecutive quads of a plane's row-major quad index (it may run over the end of a quad row into the next:
+  // every lane holds a quad even when a row is not a multiple of 64 quads wide); tile order: channel group, time, tile of
+  // the plane, sample
+  const int nq = a.R * a.Cq;                        // quads of a plane
+  auto decode = [&](int tile, int& b, int& t, int& tp, int& yb) __attribute__((always_inline)) {
     yb = tile % a.gridy;
     int r = tile / a.gridy;
     t = r % a.T; r /= a.T;
-    tw = r % a.ntq; r /= a.ntq;
-    Rr = r % a.R;
-    b = r / a.R;
+    tp = r % a.ntq;
+    b = r / a.ntq;
   };
-  auto span_lo4 = [&](int Rr, int tw) __attribute__((always_inline)) -> int {
-    const int lo = (2 * Rr - 1) * W + 2 * tw * a.tqw - 1;       // first input element of the tile (odd)
+  auto span_lo4 = [&](int tp) __attribute__((always_inline)) -> int {
+    const int Q0 = tp * 64, R0 = Q0 / a.Cq, c0 = Q0 - R0 * a.Cq;
+    const int lo = (2 * R0 - 1) * W + 2 * c0 - 1;               // first input element of the tile (odd)
     return lo >= 0 ? (lo & ~3) : -((3 - lo) & ~3);
   };
   // staging state of a tile: sample / plane of the tile, this lane's 16-byte group of the staged span
   struct StageT { int b, t; unsigned voff; bool ok; };
   auto stage_setup = [&](int tile) __attribute__((always_inline)) -> StageT {
     StageT q;
-    int Rr, tw, yb;
-    decode(tile, q.b, q.t, Rr, tw, yb);
-    const int lo4 = span_lo4(Rr, tw);
-    int whi = 2 * (tw + 1) * a.tqw;
-    if (whi > W) whi = W;
-    const int hi = (2 * Rr + 2) * W + whi + 1;                   // one past the last input element
+    int tp, yb;
+    decode(tile, q.b, q.t, tp, yb);
+    const int lo4 = span_lo4(tp);
+    int Ql = tp * 64 + 63;
+    if (Ql > nq - 1) Ql = nq - 1;
+    const int R1 = Ql / a.Cq, c1 = Ql - R1 * a.Cq;
+    const int hi = (2 * R1 + 2) * W + 2 * c1 + 3;                // one past the last input element
     const int ng = (hi - lo4 + 3) >> 2;
     const int i0 = lo4 + 4 * tid;
     q.ok = tid < ng && i0 >= 0 && i0 + 4 <= HWp;                 // (H*W and lo4 are multiples of 4: a group is all in or all out)
@@ -174,25 +181,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
   bool c_vq = false;
   auto read_setup = [&](int tile) __attribute__((always_inline)) -> ReadT {
     ReadT q;
-    int b, t, Rr, tw, yb;
-    decode(tile, b, t, Rr, tw, yb);
-    const int qi = nw * 32 + l31;
-    const int w = 2 * (tw * a.tqw + qi);
-    const int lo = (2 * Rr - 1) * W + 2 * tw * a.tqw - 1;
-    const int sh = lo - span_lo4(Rr, tw) + 1;                    // 2 or 4: image offset of the tile's first input
-    q.base = half * 3 * PL + sh + 2 * qi;                        // + (2 cp * 3 + dt) * PL + r * W + c
+    int b, t, tp, yb;
+    decode(tile, b, t, tp, yb);
+    int Q = tp * 64 + nw * 32 + l31;
+    if (Q > nq - 1) Q = nq - 1;                                  // lanes past the plane's last quad read (and discard) its patch
+    const int Rq = Q / a.Cq, w = 2 * (Q - Rq * a.Cq);
+    q.base = half * 3 * PL + 1 + ((2 * Rq - 1) * W + w - 1 - span_lo4(tp));   // even; + (2 cp * 3 + dt) * PL + r * W + c
     q.f0 = w == 0 ? 0.f : 1.f;
     q.f3 = w + 2 >= W ? 0.f : 1.f;
     return q;
   };
   auto cmp_setup = [&](int tile) __attribute__((always_inline)) {
-    int Rr, tw;
-    decode(tile, c_b, c_t, Rr, tw, c_yb);
-    const int qi = nw * 32 + l31;
-    const int cq = tw * a.tqw + qi;
-    c_vq = qi < a.tqw && cq < a.Cq;
-    c_h = 2 * Rr;
-    c_w = 2 * cq;
+    int tp;
+    decode(tile, c_b, c_t, tp, c_yb);
+    const int Q = tp * 64 + nw * 32 + l31;
+    c_vq = Q < nq;
+    const int Rq = Q / a.Cq;
+    c_h = 2 * Rq;
+    c_w = 2 * (Q - Rq * a.Cq);
   };
   // first plane (channel 4 sc, time t - 1) of a sub-chunk of a staged tile; the 12 planes follow at (cc * T + dt) * HWb
   const long THWb = (long)a.T * HWb;
