@@ -1273,7 +1273,7 @@ int g_wino2d = 0;
 struct W2Geom { int Cq, R, ntq, tqw, gridy, nsc, ntl; bool ok; };
 inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   W2Geom q{};
-  if (!conv_is_wino2d(Cin, Cout, KT) || (W & 1) || (((long)H * W) & 3) || W < 2) return q;
+  if (!conv_is_wino2d(Cin, Cout, KT) || (W & 1) || W < 2 || (long)H * W < 4) return q;
   q.Cq = W / 2;
   q.R = hpvg_cdiv(H, 2);
   const int nq = q.R * q.Cq;

@@ -22,8 +22,8 @@
 //  * every vector-memory instruction of the loop is inline asm and the waits are counted by hand (both queues return in
 //    order): the compiler would otherwise drain the LDS-DMA queue in front of every use of a loaded U fragment
 //    (cdna_hip_programming.md, "Pipelining across barriers").  Count rules are next to WAIT_A below.
-// Eligibility (conv_use_wino2d): 3x3x3, Cin >= 8, Cout > 32, even W, H*W a multiple of 4 (16-byte groups never straddle
-// the end of a plane), a staged span of at most 256 groups (W <= 298; <= ~210 when tiles wrap over quad rows), enough
+// Eligibility (conv_use_wino2d): 3x3x3, Cin >= 8, Cout > 32, even W (a 16-byte group never straddles the START of a plane;
+// the one that straddles its end when H*W = 2 (mod 4) is patched in by stage_tail), a staged span of at most 256 groups (W <= 298; <= ~210 when tiles wrap over quad rows), enough
 // tiles to fill the chip several times.
 
 struct Wino2Args {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     return lo >= 0 ? (lo & ~3) : -((3 - lo) & ~3);
   };
   // staging state of a tile: sample / plane of the tile, this lane's 16-byte group of the staged span
-  struct StageT { int b, t; unsigned voff; bool ok; };
+  struct StageT { int b, t; unsigned voff; bool ok; int tail; };
   auto stage_setup = [&](int tile) __attribute__((always_inline)) -> StageT {
     StageT q;
     int tp, yb;
@@ -170,9 +170,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     const int hi = (2 * R1 + 2) * W + 2 * c1 + 3;                // one past the last input element
     const int ng = (hi - lo4 + 3) >> 2;
     const int i0 = lo4 + 4 * tid;
-    q.ok = tid < ng && i0 >= 0 && i0 + 4 <= HWp;                 // (H*W and lo4 are multiples of 4: a group is all in or all out)
+    q.ok = tid < ng && i0 >= 0 && i0 + 4 <= HWp;                 // a group is loaded when it lies wholly inside the plane
     q.voff = q.ok ? (unsigned)i0 * 4u : 0u;
+    // H*W = 2 (mod 4): the group that holds the plane's last two elements also holds two of the next plane (or of nothing:
+    // the end of the tensor), so it is zero-sourced like every group outside; the tile that stages it patches the two
+    // elements in afterwards (stage_tail)
+    const int gt = (HWp - lo4) >> 2;
+    q.tail = ((HWp & 3) != 0 && gt < ng) ? gt : -1;
     return q;
+  };
+  // the two elements stage_setup's `tail` group lost, for the 12 planes of sub-chunk sc of tile q in buffer bf: an ordinary
+  // in-bounds 8-byte load and an LDS write by the lane that owns the group, after the buffer's DMA pieces have landed
+  // (a later piece would overwrite them with zeros) and before the barrier that publishes it.  Rare (one tile per plane)
+  // and compiler-visible: its waits are the compiler's
+  auto stage_tail = [&](const StageT& q, int sc, int bf) __attribute__((always_inline)) {
+    if (q.tail < 0) return;
+    if (tid == q.tail) {
+      const char* p0 = reinterpret_cast<const char*>(a.x) + (((long)q.b * a.Cin + (long)sc * 4) * a.T + (q.t - 1)) * HWb;
+#pragma unroll 1
+      for (int pl = 0; pl < 12; ++pl) {
+        const int cc = pl / 3, dt = pl - 3 * cc;
+        const int tt = q.t + dt - 1;
+        if (sc * 4 + cc < a.Cin && tt >= 0 && tt < a.T) {
+          const float* src = reinterpret_cast<const float*>(p0 + ((long)cc * a.T + dt) * HWb) + (HWp - 2);
+          float* dst = xs + bf * BUFF + pl * PL + 1 + 4 * q.tail;
+          dst[0] = src[0];
+          dst[1] = src[1];
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   };
 
   // compute state of a tile: where this lane's quad is (epilogue) and how it reads its patches (K loop)
@@ -256,6 +283,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_tail(st_cur, 0, 0);
   asm volatile("s_barrier" ::: "memory");
   {
     const f32x2a* xl0 = reinterpret_cast<const f32x2a*>(xs + rd_cur.base);
@@ -359,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
       W2_STEP(4, 32)
 #ifndef HPVG_ABL2_NOBAR
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      stage_tail(wrap ? st_nxt : st_cur, nsc_i, nb);
       asm volatile("s_barrier" ::: "memory");   // buffer nb is complete for every wave (and everybody is past the item before)
 #endif
       W2_STEP(5, 32)

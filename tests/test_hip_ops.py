@@ -174,6 +174,9 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
 @pytest.mark.parametrize("B,Cin,Cout,sp", [
     (1, 64, 64, (2, 4, 6)), (2, 64, 64, (3, 6, 8)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 10, 40, (3, 4, 4)),
     (2, 64, 64, (5, 36, 130)), (1, 64, 64, (2, 9, 256)), (1, 12, 64, (2, 2, 2)), (2, 64, 64, (3, 57, 104)), (1, 64, 64, (14, 23, 40)),
+    # H*W = 2 (mod 4): the 16-byte group at the end of a plane is patched in by the tile that stages it (stage_tail); with
+    # several tiles per plane, tiny planes, the last plane of the tensor (nothing may be read past it) and an odd height
+    (1, 64, 64, (3, 57, 102)), (2, 16, 40, (2, 3, 2)), (1, 64, 64, (5, 7, 6)), (2, 64, 64, (2, 91, 162)), (1, 64, 64, (3, 1, 2)),
 ])
 def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
     """conv_wino2d_kernel (F(2x2, 3x3) over H and W, one workgroup per CU, software-pipelined with hand-counted waits;
