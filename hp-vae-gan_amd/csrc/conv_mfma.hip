@@ -1303,10 +1303,13 @@ inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT)
 // workgroup per CU and no stream-K want a few rounds of tiles - stage 9 (14.6 rounds at B = 2): 1.05 vs 1.31 ms for the
 // one-axis kernel + fix-up; stage 8 (5 rounds): 0.354 vs 0.458 (0.53 while its tiles were cut per quad row and filled 51
 // of their 64 quads).
-constexpr long W2_MIN_TILES = 4L * HPVG_NUM_CU;
+// Measured around the edge (stage 7, 826 tiles per sample pair): B = 2, 3.2 rounds -> 4 (81 % full): 0.320 vs 0.307 ms, loses;
+// B = 3, 4.8 -> 5 (97 %): x1.18; B = 4, 6.5 -> 7 (92 %): x1.11.  Rule: at least three rounds, filled to 88 % or more.
 inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
-  return g_wino2d == 2 || q.ntl >= W2_MIN_TILES;
+  if (g_wino2d == 2) return true;
+  const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
+  return rounds >= 3 && (double)q.ntl >= 0.88 * (double)(rounds * HPVG_NUM_CU);
 }
 template <int VAR>
 int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
