@@ -1311,10 +1311,10 @@ inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
   return rounds >= 3 && (double)q.ntl >= 0.88 * (double)(rounds * HPVG_NUM_CU);
 }
-template <int VAR>
-int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
+template <int VAR, bool TAIL>
+int launch_wino2d_inst(const Wino2Args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_wino2d_kernel<VAR>;
+  auto kern = conv_wino2d_kernel<VAR, TAIL>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       (void)hipGetLastError();
@@ -1323,6 +1323,11 @@ int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
   const int S = a.ntl < HPVG_NUM_CU ? a.ntl : HPVG_NUM_CU;
   hipLaunchKernelGGL(kern, dim3(S), dim3(256), (size_t)3 * 12 * W2_PL * sizeof(float), s, a);   // three input buffers
   return hpvg_launch_status();
+}
+
+template <int VAR>
+int launch_wino2d_var(const Wino2Args& a, hipStream_t s) {
+  return (((long)a.H * a.W) & 3) ? launch_wino2d_inst<VAR, true>(a, s) : launch_wino2d_inst<VAR, false>(a, s);
 }
 
 // The search costs ~10-20 us of host time; shapes repeat every iteration, so plans are memoised (host-side, tiny).

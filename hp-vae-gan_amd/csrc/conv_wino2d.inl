@@ -114,7 +114,10 @@ __device__ __forceinline__ void w2_load_a(f32x4& dst, unsigned voff, const char*
 #else
 #define W2_ABL_LOADA(D, O, B) w2_load_a(D, O, B)
 #endif
-template <int VAR>
+// TAIL: the plane size is 2 (mod 4) and the group cut by the plane end needs stage_tail - a separate instance, so that the
+// usual one carries none of that code (present but never executed it cost the bit-mask variant 13 % through register
+// allocation)
+template <int VAR, bool TAIL>
 __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     // the end of the tensor), so it is zero-sourced like every group outside; the tile that stages it patches the two
     // elements in afterwards (stage_tail)
     const int gt = (HWp - lo4) >> 2;
-    q.tail = ((HWp & 3) != 0 && gt < ng) ? gt : -1;
+    q.tail = TAIL ? __builtin_amdgcn_readfirstlane(gt < ng ? gt : -1) : -1;   // uniform: keep it scalar
     return q;
   };
   // the two elements stage_setup's `tail` group lost, for the 12 planes of sub-chunk sc of tile q in buffer bf: an ordinary
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  stage_tail(st_cur, 0, 0);
+  if constexpr (TAIL) stage_tail(st_cur, 0, 0);
   asm volatile("s_barrier" ::: "memory");
   {
     const f32x2a* xl0 = reinterpret_cast<const f32x2a*>(xs + rd_cur.base);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
       W2_STEP(4, 32)
 #ifndef HPVG_ABL2_NOBAR
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      stage_tail(wrap ? st_nxt : st_cur, nsc_i, nb);
+      if constexpr (TAIL) stage_tail(wrap ? st_nxt : st_cur, nsc_i, nb);
       asm volatile("s_barrier" ::: "memory");   // buffer nb is complete for every wave (and everybody is past the item before)
 #endif
       W2_STEP(5, 32)
