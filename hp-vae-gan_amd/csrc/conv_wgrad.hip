@@ -34,6 +34,7 @@ struct WgradArgs {
   int Th, Tw, RS, DS, XS, QK, nth, ntw, S, ncb, nob;
   int S0;  // KT == 3: persistent slots of the outer time taps (dt = 0, 2); the centre tap has S (>= S0)
   int in_lrelu;
+  float* bpart;  // conv_wgradw_kernel only (else unused): [S][nob][64] per-slot sums of dY over the slot's tiles - the bias gradient
 };
 
 
@@ -1179,7 +1180,9 @@ WPlan plan_wgradw(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (filled < NE) cache[filled++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
   return p;
 }
-inline size_t wgradw_ws_bytes(const WPlan& p, int KT) { return 256 + (size_t)p.S * KT * p.nob * p.ncb * 12 * 4096 * sizeof(float); }
+inline size_t wgradw_slab_bytes(const WPlan& p, int KT) { return (size_t)p.S * KT * p.nob * p.ncb * 12 * 4096 * sizeof(float); }
+// (+ the per-slot bias partials [S][nob][64] behind the slabs)
+inline size_t wgradw_ws_bytes(const WPlan& p, int KT) { return 256 + wgradw_slab_bytes(p, KT) + (size_t)p.S * p.nob * 64 * sizeof(float); }
 // HPVG_WGRAD_WINO (read once; hpvg_conv_bwd_weight_wino_config changes it at run time): 0 = never the Winograd weight
 // gradient, 2 = every wide layer, 1 / unset = by size (see wgradw_wanted)
 int g_wgradw_mode = -1;
@@ -1312,9 +1315,32 @@ size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int
 }
 
 // dw: natural layout [Cout][Cin][KT][3][3]; accumulate != 0 adds into dw instead of overwriting.
+static int bwd_weight_impl(const float* dy, const float* x, const float* in_scale, const float* in_shift, int in_lrelu,
+                           float* dw, int accumulate, float* db, int accumulate_db, void* ws, size_t ws_bytes, int B, int Cin,
+                           int Cout, int T, int H, int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_scale, const float* in_shift, int in_lrelu,
                              float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
                              int W, int KT, void* stream) {
+  return bwd_weight_impl(dy, x, in_scale, in_shift, in_lrelu, dw, accumulate, nullptr, 0, ws, ws_bytes, B, Cin, Cout, T, H, W, KT,
+                         stream);
+}
+// does hpvg_conv_bwd_weight_bias_f32 produce the bias gradient for this layer (the Winograd weight-gradient kernel runs it)?
+int hpvg_conv_bwd_weight_fuses_bias(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3) || narrow_mode(Cin, Cout) >= 0) return 0;
+  return wgradw_wanted(plan_wgradw(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT) ? 1 : 0;
+}
+// the weight gradient AND db[o] (+)= sum over batch and positions of dy - the conv's bias gradient - from the same launch:
+// the centre-tap workgroups of conv_wgradw_kernel hold every dY pair in registers anyway.  HPVG_ERR_UNSUPPORTED where
+// hpvg_conv_bwd_weight_fuses_bias() says 0 (the caller then uses hpvg_channel_sum_f32).
+int hpvg_conv_bwd_weight_bias_f32(const float* dy, const float* x, float* dw, int accumulate, float* db, int accumulate_db, void* ws,
+                                  size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT, void* stream) {
+  if (!db) return HPVG_ERR_ARG;
+  if (!hpvg_conv_bwd_weight_fuses_bias(B, Cin, Cout, T, H, W, KT)) return HPVG_ERR_UNSUPPORTED;
+  return bwd_weight_impl(dy, x, nullptr, nullptr, 0, dw, accumulate, db, accumulate_db, ws, ws_bytes, B, Cin, Cout, T, H, W, KT, stream);
+}
+static int bwd_weight_impl(const float* dy, const float* x, const float* in_scale, const float* in_shift, int in_lrelu,
+                           float* dw, int accumulate, float* db, int accumulate_db, void* ws, size_t ws_bytes, int B, int Cin,
+                           int Cout, int T, int H, int W, int KT, void* stream) {
   if (!dy || !x || !dw || !ws) return HPVG_ERR_ARG;
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
   if (KT != 1 && KT != 3) return HPVG_ERR_UNSUPPORTED;
@@ -1409,6 +1435,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
       a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
       a.Th = pw.Th; a.Tw = pw.Tw; a.RS = pw.RS; a.DS = pw.DS; a.XS = pw.XS; a.QK = pw.QK; a.nth = pw.nth; a.ntw = pw.ntw;
       a.S = pw.S; a.S0 = pw.S0; a.ncb = pw.ncb; a.nob = pw.nob; a.in_lrelu = 0;
+      a.bpart = db ? (float*)((char*)ws + 256 + wgradw_slab_bytes(pw, KT)) : nullptr;
       hipStream_t s = (hipStream_t)stream;
       const dim3 grid((KT == 3 ? 2 * pw.S0 + pw.S : pw.S) * pw.nob * pw.ncb);
       const int njd = pw.DS > 256 ? 2 : 1, njx = pw.XS > 256 ? 2 : 1;
@@ -1436,11 +1463,13 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
       int stw = hpvg_launch_status();
       if (stw != HPVG_OK) return stw;
       const long totw = (long)KT * pw.nob * pw.ncb * 3 * 4096;
-      hipLaunchKernelGGL(conv_wgradw_reduce_kernel, dim3(hpvg_cdiv(totw, 128)), dim3(128, 8), 0, s, (const float*)a.part, dw, pw.S, pw.S0,
-                         KT, pw.nob, pw.ncb, Cout, Cin, accumulate);
+      const int nbw = hpvg_cdiv(totw, 128);
+      hipLaunchKernelGGL(conv_wgradw_reduce_kernel, dim3(nbw + (db ? hpvg_cdiv(Cout, 128) : 0)), dim3(128, 8), 0, s, (const float*)a.part,
+                         dw, pw.S, pw.S0, KT, pw.nob, pw.ncb, Cout, Cin, accumulate, nbw, (const float*)a.bpart, db, accumulate_db);
       return hpvg_launch_status();
     }
   }
+  if (db) return HPVG_ERR_UNSUPPORTED;   // (only the Winograd kernel above produces the bias gradient)
   if (KT == 3) {
     const W3Plan q = plan_wgrad3(B, Cin, Cout, T, H, W);
     if (wgrad3_wanted(q)) {
@@ -1478,7 +1507,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
   a.part = (float*)((char*)ws + 256);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
   a.Th = p.Th; a.Tw = p.Tw; a.RS = p.RS; a.DS = p.DS; a.XS = p.XS; a.QK = p.QK; a.nth = p.nth; a.ntw = p.ntw;
-  a.S = p.S; a.S0 = p.S0; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu;
+  a.S = p.S; a.S0 = p.S0; a.ncb = p.ncb; a.nob = p.nob; a.in_lrelu = in_lrelu; a.bpart = nullptr;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((KT == 3 ? 2 * p.S0 + p.S : p.S) * p.nob * p.ncb);
   const int njd = p.DS > 256 ? 2 : 1, njx = p.XS > 256 ? 2 : 1;

@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   for (int k = 0; k < 12; ++k)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+  // Bias gradient on the side (a.bpart): db[o] = sum of dY[o] over batch and positions.  The centre-tap workgroups walk every
+  // tile, and the waves of their first input-channel half hold y0 + y1 of every dY pair of their 32 output channels (the
+  // Winograd Y_1): one more add per K step.  Per tile in fp32, tiles added with Kahan compensation (a lane sums thousands
+  // of values), slots summed in double by the reduce kernel.
+  const float bflag = (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) ? 1.f : 0.f;
+  float bsum = 0.f, brun = 0.f, bcomp = 0.f;
 
   // zero both buffers once: rows of absent channels are never written afterwards
   for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   {                                                                                                                \
     const float y0_ = A[0], y1_ = A[1];                                                                            \
     const float ys_ = y0_ + y1_, yd_ = y0_ - y1_, yn_ = -y1_;                                                      \
+    bsum = __builtin_fmaf(bflag, ys_, bsum);                                                                       \
     _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                                             \
       const float d0_ = B0[dh][0], d1_ = B0[dh][1], d2_ = B1[dh][0], d3_ = B1[dh][1];                              \
       acc[dh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0_, d0_ - d2_, acc[dh * 4 + 0], 0, 0, 0);            \
@@ -215,11 +222,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
 #undef WW_LOAD
 #undef WW_MMA
     }
+    {   // this tile's bias sum into the running one (Kahan)
+      const float yk = bsum - bcomp, tk = brun + yk;
+      bcomp = (tk - brun) - yk;
+      brun = tk;
+      bsum = 0.f;
+    }
     while (cnext < 64) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
     __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
     cur ^= 1;
   }
 
+  if (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) {
+    // the two half-waves hold the even / odd pairs of the same channels
+    const float tot = brun + __shfl_xor(brun, 32, 64);
+    if (half == 0) a.bpart[((long)slot * a.nob + ob) * 64 + oblk * 32 + l31] = active ? tot : 0.f;
+  }
   // ---- partial slab: part[s][dt][z][dh*4 + j][o64][c64]
   float* pp = a.part + ((((long)slot * KT + dt) * nz + z) * 12) * 4096;
 #pragma unroll
@@ -236,9 +254,37 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
 // sums are added in group order through LDS (reproducible), then the output transform.
 __global__ __launch_bounds__(1024) void conv_wgradw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S1,
                                                                   int S0, int KT, int nob, int ncb, int Cout, int Cin,
-                                                                  int accumulate) {
+                                                                  int accumulate, int nbw, const float* __restrict__ bpart,
+                                                                  float* __restrict__ db, int accumulate_db) {
   __shared__ float sm[8][4][128];
   const int g = threadIdx.y;
+  if ((int)blockIdx.x >= nbw) {
+    // the bias gradient: db[o] = sum over the centre tap's S1 slots of bpart[slot][o / 64][o % 64]: eight slot groups in slot
+    // order (two chains each), the group sums in group order through LDS, in double
+    double* smd = reinterpret_cast<double*>(&sm[0][0][0]);     // [8][128] doubles
+    const int o = ((int)blockIdx.x - nbw) * 128 + threadIdx.x;
+    double t0 = 0.0, t1 = 0.0;
+    if (o < Cout) {
+      const float* q = bpart + (long)(o / 64) * 64 + (o & 63);
+      const long sstride = (long)nob * 64;
+      int sl = (int)((long)g * S1 / 8);
+      const int hi = (int)((long)(g + 1) * S1 / 8);
+      for (; sl + 2 <= hi; sl += 2) {
+        t0 += (double)q[(long)sl * sstride];
+        t1 += (double)q[(long)(sl + 1) * sstride];
+      }
+      if (sl < hi) t0 += (double)q[(long)sl * sstride];
+    }
+    smd[g * 128 + threadIdx.x] = t0 + t1;
+    __syncthreads();
+    if (g == 0 && o < Cout) {
+      double t = smd[threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += smd[k * 128 + threadIdx.x];
+      db[o] = accumulate_db ? db[o] + (float)t : (float)t;
+    }
+    return;
+  }
   const long idx = (long)blockIdx.x * 128 + threadIdx.x;
   const long per_s = (long)KT * nob * ncb * 12 * 4096;
   const long total = (long)KT * nob * ncb * 3 * 4096;

@@ -47,6 +47,8 @@ _SIGS = {
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_wino_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_wino_config": [I],
+    "hpvg_conv_bwd_weight_fuses_bias": [I, I, I, I, I, I, I],
+    "hpvg_conv_bwd_weight_bias_f32": [P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_channel_sum_ws_bytes": [I],
     "hpvg_channel_sum_f32": [P, P, I, P, Z, I, I, L, P],
     "hpvg_bn_ws_bytes": [I],

@@ -267,6 +267,23 @@ def conv_bwd_weight_raw(dy, x, w_shape, into=None):
     return None if into is not None else dw
 
 
+def conv_bwd_weight_bias_raw(dy, x, w_shape, into_w, into_b):
+    """dw AND the bias gradient from one launch where the library can (wide layers on the Winograd weight-gradient kernel),
+    both added into their gradient buffers; returns False when the layer is not one of those (nothing was launched)."""
+    dy = _c(dy)
+    x = _c(x)
+    B, Co, T, H, W = geom(dy)
+    Ci = x.shape[1]
+    KT = _kt(w_shape)
+    if load().hpvg_conv_bwd_weight_fuses_bias(B, Ci, Co, T, H, W, KT) != 1:
+        return False
+    nbytes = call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT)
+    ws = workspace(nbytes, dy.device)
+    call("hpvg_conv_bwd_weight_bias_f32", ptr(dy), ptr(x), ptr(into_w), 1, ptr(into_b), 1, ptr(ws), ctypes.c_size_t(ws.numel()),
+         B, Ci, Co, T, H, W, KT, stream())
+    return True
+
+
 def channel_sum_raw(dy, into=None):
     dy = _c(dy)
     B, C, T, H, W = geom(dy)
@@ -385,9 +402,16 @@ class Conv(Function):
             dy = LReLUMaskMul.apply(dy, y)
         params = not inputs_only.active
         dx = ConvBwdData.apply(dy, w, x if ctx.in_act else None, in_bits) if ctx.needs_input_grad[0] else None
-        dw = _weight_grad(dy, x, w) if (ctx.needs_input_grad[1] and params) else None
+        want_w = ctx.needs_input_grad[1] and params
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and params
+        if want_w and want_b:
+            # both straight into their gradient buffers from ONE launch where the library fuses them
+            ws_, bs_ = grad_slot(w), grad_slot(b)
+            if ws_ is not None and bs_ is not None and conv_bwd_weight_bias_raw(dy, x, w.shape, ws_, bs_):
+                return dx, None, None, None, None, None, None
+        dw = _weight_grad(dy, x, w) if want_w else None
         db = None
-        if ctx.has_bias and ctx.needs_input_grad[2] and params:
+        if want_b:
             slot = grad_slot(b)
             db = channel_sum_raw(dy, into=slot) if slot is not None else ChannelSum.apply(dy)
         return dx, dw, db, None, None, None, None

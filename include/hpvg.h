@@ -98,6 +98,13 @@ int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int
  * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never, 1 = by size, 2 = every wide
  * layer; negative = query.  Returns the mode in force.  Host only. */
 int hpvg_conv_bwd_weight_wino_config(int mode);
+/* The weight gradient and the conv's bias gradient db[o] (+)= sum_{b,positions} dy[b][o] from ONE launch, for the layers
+ * hpvg_conv_bwd_weight_fuses_bias() reports 1 for (the Winograd weight-gradient kernel runs them: its centre-tap workgroups
+ * hold every dy pair in registers anyway); HPVG_ERR_UNSUPPORTED elsewhere (use hpvg_channel_sum_f32).  Same workspace as
+ * hpvg_conv_bwd_weight_f32.  Reference: the bias half of aten::convolution_backward, train_video.py:182,200. */
+int hpvg_conv_bwd_weight_fuses_bias(int B, int Cin, int Cout, int T, int H, int W, int KT);
+int hpvg_conv_bwd_weight_bias_f32(const float* dy, const float* x, float* dw, int accumulate, float* db, int accumulate_db, void* ws,
+                                  size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient.  accumulate != 0: out[c] += (the caller passes the parameter's
  * gradient buffer, which removes autograd's AccumulateGrad add kernel) */

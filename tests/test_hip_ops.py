@@ -243,12 +243,22 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     prev = lib.hpvg_conv_bwd_weight_wino_config(-1)
     res = {}
     try:
+        want_db = gy.sum(dim=[0] + list(range(2, 2 + nd)))
+        bbase = _rand(Cout, seed=35).to(DEV)
         for mode in (2, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
             assert ops.conv_bwd_weight_raw(gyd, xd, w.shape, into=acc) is None
             res[mode] = (dw, acc)
+            # weight AND bias gradient from one launch (the Winograd kernel's centre-tap workgroups sum dY on the side)
+            accw, accb = base.clone(), bbase.clone()
+            fused = ops.conv_bwd_weight_bias_raw(gyd, xd, w.shape, accw, accb)
+            assert fused == (mode == 2 and Cin > 4 and Cout > 4)
+            if fused:
+                assert_close(accw - base, want, RTOL, "wino.fused.dw", atol=1e-5 * float(base.abs().max()))
+                assert_close(accb - bbase, want_db, 1e-5, "wino.fused.db", atol=2e-6 * float(bbase.abs().max()))
+                assert torch.equal(accw, acc)      # the same weight-gradient launch, bit for bit
     finally:
         lib.hpvg_conv_bwd_weight_wino_config(prev)
     for mode, (dw, acc) in res.items():
