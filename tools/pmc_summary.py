@@ -39,7 +39,7 @@ if json_out:
     # (the Winograd kernel when the library runs the shape on it - conv_wino_kernel<3, 2, 0> - else the direct one)
     # (the kernel the library runs the shape on: two-axis Winograd conv_wino2d_kernel<0> - whole tiles, no fix-up launch -,
     # else one-axis conv_wino_kernel<3, 2, 0, *>, else the direct one)
-    w2 = [k for k in rows if "conv_wino2d_kernel<0>" in k[0]]
+    w2 = [k for k in rows if "conv_wino2d_kernel<0" in k[0]]
     wino = [k for k in rows if "conv_wino_kernel<" in k[0] and ", 0, " in k[0]]
     if w2:
         main = max(w2, key=lambda k: rows[k])
