@@ -21,7 +21,10 @@ for i, (s, e, n) in enumerate(rows):
         else:
             fix.append((e - s) / 1e3)
 print("kernel:", key, " launches:", len(main))
-edges = [0, 100, 300, 600, 1000, 1500, 2500, 1e9]  # 1.5-2.5 ms: the B = 2 finest-level launches (the roofline shape); above: B = 4 (merged generator pass)
+# (direct kernel: 1.5-2.5 ms = the B = 2 finest-level launches, the roofline shape; above: B = 4, the merged generator pass.
+#  two-axis Winograd kernel, key "conv_wino2d_kernel<0": 0.9-1.3 ms = B = 2 at 13 x 144 x 256, ~2.1 ms = B = 4; below 0.9: the
+#  level-8 volume inside a stage-9 iteration)
+edges = [0, 100, 300, 600, 900, 1300, 1500, 2500, 1e9]
 for lo, hi in zip(edges[:-1], edges[1:]):
     sel = [(m, f) for m, f in zip(main, fix) if lo <= m < hi]
     if sel:
