@@ -1439,26 +1439,34 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       hipStream_t s = (hipStream_t)stream;
       const dim3 grid((KT == 3 ? 2 * pw.S0 + pw.S : pw.S) * pw.nob * pw.ncb);
       const int njd = pw.DS > 256 ? 2 : 1, njx = pw.XS > 256 ? 2 : 1;
-#define HPVG_WW_LAUNCH(K, D, X)                                                                                        \
+      // whole channel rows per wave (WCH) where an instance exists for the row lengths: pieces of 64 lanes
+      const int wjd = hpvg_cdiv(pw.DS, 64), wjx = hpvg_cdiv(pw.XS, 64);
+      static const int wch_mode = [] { const char* e = getenv("HPVG_WGRADW_WCH"); return e ? atoi(e) : 1; }();
+#define HPVG_WW_LAUNCH(K, D, X, C)                                                                                     \
   {                                                                                                                    \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X>),                              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X, C>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
         (void)hipGetLastError();                                                                                       \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X>), grid, dim3(256), pw.lds, s, a);                                  \
+    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X, C>), grid, dim3(256), pw.lds, s, a);                               \
   }
+#define HPVG_WW_WCH(K)                                                                                                 \
+  if (wch_mode && wjd == 1 && wjx == 2) HPVG_WW_LAUNCH(K, 1, 2, true)                                                  \
+  else if (wch_mode && wjd == 1 && wjx == 3) HPVG_WW_LAUNCH(K, 1, 3, true)                                             \
+  else if (wch_mode && wjd == 2 && wjx == 3) HPVG_WW_LAUNCH(K, 2, 3, true)                                             \
+  else if (wch_mode && wjd == 2 && wjx == 4) HPVG_WW_LAUNCH(K, 2, 4, true)                                             \
+  else if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(K, 1, 1, false)                                                        \
+  else if (njd == 1) HPVG_WW_LAUNCH(K, 1, 2, false)                                                                    \
+  else HPVG_WW_LAUNCH(K, 2, 2, false)
       if (KT == 3) {
-        if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(3, 1, 1)
-        else if (njd == 1) HPVG_WW_LAUNCH(3, 1, 2)
-        else HPVG_WW_LAUNCH(3, 2, 2)
+        HPVG_WW_WCH(3)
       } else {
-        if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(1, 1, 1)
-        else if (njd == 1) HPVG_WW_LAUNCH(1, 1, 2)
-        else HPVG_WW_LAUNCH(1, 2, 2)
+        HPVG_WW_WCH(1)
       }
+#undef HPVG_WW_WCH
 #undef HPVG_WW_LAUNCH
       int stw = hpvg_launch_status();
       if (stw != HPVG_OK) return stw;

@@ -21,12 +21,21 @@ typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
 // development ablation (timing only, results wrong): -DHPVG_ABLW_NODMA stages nothing from inside the K loop
 #ifdef HPVG_ABLW_NODMA
 #define WGW_ABL_DY {}
-#define WGW_ABL_XX { if (cnext < 64) ++cnext; }
+#define WGW_ABL_XX { if (cnext < NCH) ++cnext; }
+#define WGW_ABL_PIECE(Q) { if (cnext < NCH && (Q) == NP - 1) ++cnext; }
 #else
-#define WGW_ABL_DY { if (cnext < 64) dma_dy(cnext); }
-#define WGW_ABL_XX { if (cnext < 64) { dma_xx(cnext); ++cnext; } }
+#define WGW_ABL_DY { if (cnext < NCH) dma_dy(cnext); }
+#define WGW_ABL_XX { if (cnext < NCH) { dma_xx(cnext); ++cnext; } }
+#define WGW_ABL_PIECE(Q) dma_piece(Q);
 #endif
-template <int KT, int NJD, int NJX>
+// WCH = false: all four waves stage every channel row (lane p of the workgroup moves element p: 64 x 2 pieces of 256 bytes per
+// wave and tile, about half of their lanes idle).  WCH = true: wave w stages the WHOLE rows of channels w, w + 4, ... in
+// NJD + NJX pieces of 64 lanes (16 x (NJD + NJX) pieces per wave and tile, one behind each MFMA from the second one of a K
+// step on, two channels per step when they fit), so the pieces are fewer and the last of them is issued earlier in the K loop
+#ifndef HPVG_WCH_SPREAD
+#define HPVG_WCH_SPREAD 1
+#endif
+template <int KT, int NJD, int NJX, bool WCH>
 __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -34,6 +43,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int oblk = wave >> 1, cblk = wave & 1;
+  constexpr int NCH = WCH ? 16 : 64;          // staging calls per tile and wave
+  constexpr int LW = WCH ? 64 : 256;          // lanes that share a channel row
+  constexpr int NP = NJD + NJX;
+  const int lid = WCH ? lane : tid;
   // workgroup ids as in conv_wgrad_kernel: time tap fastest, then the persistent slot; the outer taps get S0 <= S slots
   const int nz = a.nob * a.ncb;
   const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
@@ -84,10 +97,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   unsigned dstr[NJD], xstr[NJX];
   bool dln[NJD], xln[NJX];
 #pragma unroll
-  for (int j = 0; j < NJD; ++j) dln[j] = j * 256 + tid < DS;
+  for (int j = 0; j < NJD; ++j) dln[j] = j * LW + lid < DS;
 #pragma unroll
-  for (int j = 0; j < NJX; ++j) xln[j] = j * 256 + tid < XS;
-  const unsigned cbytes = (unsigned)(cstride * 4);
+  for (int j = 0; j < NJX; ++j) xln[j] = j * LW + lid < XS;
+  const unsigned cbytes = (unsigned)(cstride * 4) * (WCH ? 4u : 1u);   // to the next channel this wave stages
   auto setup = [&](int tile) {
     const int t = tile % a.T;  // time-major tile order
     int r = tile / a.T;
@@ -98,11 +111,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     const int tt = t + dt - pt;
     const bool tok = tt >= 0 && tt < a.T;
     const int h0 = th_i * a.Th, w0 = tw_i * a.Tw;
-    const float* dyb = a.dy + (((long)b * a.Cout + ob * 64) * a.T + t) * HW;
-    const float* xb = a.x + (((long)b * a.Cin + cb * 64) * a.T + (tok ? tt : 0)) * HW;
+    const int ch0 = WCH ? wave : 0;
+    const float* dyb = a.dy + (((long)b * a.Cout + ob * 64 + ch0) * a.T + t) * HW;
+    const float* xb = a.x + (((long)b * a.Cin + cb * 64 + ch0) * a.T + (tok ? tt : 0)) * HW;
 #pragma unroll
     for (int j = 0; j < NJD; ++j) {
-      const int p = j * 256 + tid;
+      const int p = j * LW + lid;
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh, gw = w0 + ww;
       const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     }
 #pragma unroll
     for (int j = 0; j < NJX; ++j) {
-      const int p = j * 256 + tid;
+      const int p = j * LW + lid;
       const int hh = p / RS, ww = p - hh * RS;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
       const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
@@ -122,34 +136,58 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   float* dma_d = lds;
   float* dma_x = lds;
   auto dma_begin = [&](float* buf) {
-    dma_d = buf + wave * 64;
-    dma_x = buf + 64 * DS + wave * 64;
+    dma_d = buf + (WCH ? wave * DS : wave * 64);
+    dma_x = buf + 64 * DS + (WCH ? wave * XS : wave * 64);
   };
   // (the two halves of a channel are issued behind DIFFERENT MFMAs of the K loop: an LDS-DMA instruction holds the issue port
   // for about one MFMA's duration, and with one wave per SIMD whatever does not fit an MFMA's shadow stalls the matrix pipe)
   auto dma_dy = [&](int c) {
-    if (c < no) {
+    if ((WCH ? 4 * c + wave : c) < no) {
 #pragma unroll
       for (int j = 0; j < NJD; ++j) {
-        if (dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * 256), 4, 0, 0);
+        if (dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * LW), 4, 0, 0);
         dptr[j] += dstr[j];
       }
     }
-    dma_d += DS;
+    dma_d += WCH ? 4 * DS : DS;
   };
   auto dma_xx = [&](int c) {
-    if (c < nc) {
+    if ((WCH ? 4 * c + wave : c) < nc) {
 #pragma unroll
       for (int j = 0; j < NJX; ++j) {
-        if (xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * 256), 4, 0, 0);
+        if (xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * LW), 4, 0, 0);
         xptr[j] += xstr[j];
       }
     }
-    dma_x += XS;
+    dma_x += WCH ? 4 * XS : XS;
   };
   auto dma_channel = [&](int c) {
     dma_dy(c);
     dma_xx(c);
+  };
+  // WCH: piece q (dY pieces first) of the channel row(s) this wave stages next; the last piece of a row moves on
+  int cnext = NCH;                 // next staging call (NCH = nothing left)
+  auto dma_piece = [&](int q) __attribute__((always_inline)) {
+    if (cnext < NCH) {
+      const int ch = 4 * cnext + wave;
+#pragma unroll
+      for (int j = 0; j < NJD; ++j)
+        if (q == j) {
+          if (ch < no && dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * LW), 4, 0, 0);
+          dptr[j] += dstr[j];
+        }
+#pragma unroll
+      for (int j = 0; j < NJX; ++j)
+        if (q == NJD + j) {
+          if (ch < nc && xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * LW), 4, 0, 0);
+          xptr[j] += xstr[j];
+        }
+      if (q == NP - 1) {
+        dma_d += 4 * DS;
+        dma_x += 4 * XS;
+        ++cnext;
+      }
+    }
   };
 
   int tile = slot;
@@ -157,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   if (tile < ntiles) {
     setup(tile);
     dma_begin(lds);
-    for (int c = 0; c < 64; ++c) dma_channel(c);
+    for (int c = 0; c < NCH; ++c) dma_channel(c);
   }
   __syncthreads();  // (waits for the DMA: pending LDS-DMA counts on vmcnt)
 
@@ -167,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     const int next = tile + nslot;
     const bool have_next = next < ntiles;
     float* bufc = lds + cur * BUF;
-    int cnext = 64;                // next channel to stage (64 = nothing left)
+    cnext = NCH;
     if (have_next) {
       setup(next);
       dma_begin(lds + (cur ^ 1) * BUF);
@@ -191,6 +229,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   }
 // 12 MFMAs with three channels of DMA staging between them (the rate per position of conv_wgrad_kernel): a channel's dY
 // piece behind the second MFMA of a group, its X piece behind the fourth
+// staging behind MFMA M of a K step
+#define WW_AFTER(M)                                                                                                \
+  {                                                                                                                \
+    if (!WCH) {                                                                                                    \
+      if (((M) & 3) == 1) WGW_ABL_DY                                                                               \
+      if (((M) & 3) == 3) WGW_ABL_XX                                                                               \
+    } else {                                                                                                       \
+      if (HPVG_WCH_SPREAD == 0 && (M) >= 1 && (M) <= NP) WGW_ABL_PIECE((M) - 1)                                    \
+      if (HPVG_WCH_SPREAD == 0 && 2 * NP <= 11 && (M) > NP && (M) <= 2 * NP) WGW_ABL_PIECE((M) - 1 - NP)           \
+      if (HPVG_WCH_SPREAD == 1 && (M) >= 1 && (M) <= NP) WGW_ABL_PIECE((M) - 1)                                    \
+      if (HPVG_WCH_SPREAD == 2 && ((M) & 1) == 1 && ((M) >> 1) < NP) WGW_ABL_PIECE((M) >> 1)                       \
+      if (HPVG_WCH_SPREAD == 3 && ((M) % 3) == 1 && ((M) / 3) < NP) WGW_ABL_PIECE((M) / 3)                         \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  }
 #define WW_MMA(A, B0, B1)                                                                                          \
   {                                                                                                                \
     const float y0_ = A[0], y1_ = A[1];                                                                            \
@@ -199,15 +252,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                                             \
       const float d0_ = B0[dh][0], d1_ = B0[dh][1], d2_ = B1[dh][0], d3_ = B1[dh][1];                              \
       acc[dh * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0_, d0_ - d2_, acc[dh * 4 + 0], 0, 0, 0);            \
-      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      WW_AFTER(dh * 4 + 0)                                                                                         \
       acc[dh * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ys_, d1_ + d2_, acc[dh * 4 + 1], 0, 0, 0);            \
-      WGW_ABL_DY                                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      WW_AFTER(dh * 4 + 1)                                                                                         \
       acc[dh * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(yd_, d2_ - d1_, acc[dh * 4 + 2], 0, 0, 0);            \
-      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      WW_AFTER(dh * 4 + 2)                                                                                         \
       acc[dh * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yn_, d1_ - d3_, acc[dh * 4 + 3], 0, 0, 0);            \
-      WGW_ABL_XX                                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      WW_AFTER(dh * 4 + 3)                                                                                         \
     }                                                                                                              \
   }
       int st = 0;
@@ -221,6 +272,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       if (st < nsteps) WW_MMA(pa, pb0, pb1);
 #undef WW_LOAD
 #undef WW_MMA
+#undef WW_AFTER
     }
     {   // this tile's bias sum into the running one (Kahan)
       const float yk = bsum - bcomp, tk = brun + yk;
@@ -228,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       brun = tk;
       bsum = 0.f;
     }
-    while (cnext < 64) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
+    while (cnext < NCH) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
     __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
     cur ^= 1;
   }
