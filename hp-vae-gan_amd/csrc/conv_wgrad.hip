@@ -1038,6 +1038,7 @@ struct WPlan {
   int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb;
   size_t lds;
   int S0;  // slots of the outer time taps (KT == 3), <= S
+  int g16; // conv_wgradw_kernel's 16-byte staging form (RS = the X row stride Tw + 8, QK = Th * Tw)
 };
 
 WPlan plan_wgrad_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
@@ -1117,6 +1118,25 @@ WPlan plan_wgrad(int B, int Cin, int Cout, int T, int H, int W, int KT) {
 
 // Tile plan of conv_wgradw_kernel (Winograd along W): the tile family of conv_wgrad_kernel with an EVEN band width and row
 // stride, channel strides of 2 (mod 4) and the Winograd K loop's cost (12 MFMAs per 4 positions instead of 18).
+// persistent slots of a conv_wgradw_kernel plan
+void wgradw_slots(WPlan& best, int B, int T, int KT) {
+  if (!best.Th) return;
+  const long ntiles = (long)B * T * best.nth * best.ntw;
+  long cap = (long)HPVG_NUM_CU / ((long)KT * best.nob * best.ncb);  // one persistent workgroup per CU
+  if (cap < 1) cap = 1;
+  best.S = (int)(ntiles < cap ? ntiles : cap);
+  best.S0 = best.S;
+  if (KT == 3 && T >= 2 && best.S >= 2) {   // tiles-with-work per workgroup equal over the three time taps (plan_wgrad_search)
+    const long Stot = 3L * best.S;
+    long S1 = (Stot * T + (3L * T - 2) / 2) / (3L * T - 2);
+    if (S1 > ntiles) S1 = ntiles;
+    long S0 = (Stot - S1) / 2;
+    if (S0 < 1) S0 = 1;
+    if (S0 > S1) S0 = S1;
+    best.S = (int)S1;
+    best.S0 = (int)S0;
+  }
+}
 WPlan plan_wgradw_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   WPlan best{};
   double best_cost = 1e300;
@@ -1147,23 +1167,48 @@ WPlan plan_wgradw_search(int B, int Cin, int Cout, int T, int H, int W, int KT) 
       }
     }
   }
-  if (best.Th) {
-    const long ntiles = (long)B * T * best.nth * best.ntw;
-    long cap = (long)HPVG_NUM_CU / ((long)KT * nob * ncb);  // one persistent workgroup per CU
-    if (cap < 1) cap = 1;
-    best.S = (int)(ntiles < cap ? ntiles : cap);
-    best.S0 = best.S;
-    if (KT == 3 && T >= 2 && best.S >= 2) {   // tiles-with-work per workgroup equal over the three time taps (plan_wgrad_search)
-      const long Stot = 3L * best.S;
-      long S1 = (Stot * T + (3L * T - 2) / 2) / (3L * T - 2);
-      if (S1 > ntiles) S1 = ntiles;
-      long S0 = (Stot - S1) / 2;
-      if (S0 < 1) S0 = 1;
-      if (S0 > S1) S0 = S1;
-      best.S = (int)S1;
-      best.S0 = (int)S0;
+  wgradw_slots(best, B, T, KT);
+  return best;
+}
+// the 16-byte staging form (conv_wgradw_kernel<.., G16>): W a multiple of 4, bands of a multiple of 4 columns, dY rows of Tw
+// floats, X rows of Tw + 8 from column w0 - 4; at most two 64-lane pieces per channel row and operand
+int g_wgradw_g16 = -1;
+int g_wgradw_gen = 0;   // bumped when hpvg_conv_bwd_weight_wino_config changes what the planner may pick: drops the plan caches
+WPlan plan_wgradw16_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  WPlan best{};
+  if (g_wgradw_g16 < 0) {
+    const char* e = getenv("HPVG_WGRADW_G16");
+    g_wgradw_g16 = e ? atoi(e) : 1;
+  }
+  if (W % 4 != 0 || !g_wgradw_g16) return best;
+  double best_cost = 1e300;
+  const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
+  int prev_tw = 0;
+  for (int ntw = W / 4; ntw >= 1; --ntw) {
+    const int Tw = 4 * hpvg_cdiv(hpvg_cdiv(W, ntw), 4);
+    if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;
+    prev_tw = Tw;
+    const int RSx = Tw + 8;
+    for (int Th = 1; Th <= H; ++Th) {
+      const int nth = hpvg_cdiv(H, Th);
+      if (Th != hpvg_cdiv(H, nth)) continue;
+      const int QK = Th * Tw;
+      const int DS = QK + 2, XS = (Th + 2) * RSx + 2;    // both 2 (mod 4); the X rows start at float 1
+      if (Th * (Tw / 4) > 128 || (Th + 2) * (Tw / 4 + 2) > 128) break;
+      const size_t lds = (size_t)2 * 64 * (DS + XS) * sizeof(float);
+      if (lds > 156 * 1024) break;
+      const long ntiles = (long)B * T * nth * ntw;
+      double work = (double)ntiles * (QK * 0.25 * 12.0 + 40.0);
+      // development: HPVG_WG16_FORCE="Th,Tw" restricts the search to that tile
+      static const int force = [] { const char* e = getenv("HPVG_WG16_FORCE"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
+      if (force && force != Th * 1000 + Tw) continue;
+      if (work < best_cost) {
+        best_cost = work;
+        best = WPlan{Th, Tw, RSx, DS, XS, QK, nth, ntw, 0, nob, ncb, lds, 0, 1};
+      }
     }
   }
+  wgradw_slots(best, B, T, KT);
   return best;
 }
 WPlan plan_wgradw(int B, int Cin, int Cout, int T, int H, int W, int KT) {
@@ -1172,11 +1217,17 @@ WPlan plan_wgradw(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   constexpr int NE = 256;
   static thread_local Entry cache[NE];
   static thread_local int filled = 0;
+  static thread_local int gen = 0;
+  if (gen != g_wgradw_gen) {
+    gen = g_wgradw_gen;
+    filled = 0;
+  }
   for (int i = 0; i < filled; ++i) {
     const Key& c = cache[i].k;
     if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return cache[i].p;
   }
-  const WPlan p = plan_wgradw_search(B, Cin, Cout, T, H, W, KT);
+  WPlan p = plan_wgradw16_search(B, Cin, Cout, T, H, W, KT);
+  if (!p.Th) p = plan_wgradw_search(B, Cin, Cout, T, H, W, KT);
   if (filled < NE) cache[filled++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
   return p;
 }
@@ -1441,26 +1492,31 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       const int njd = pw.DS > 256 ? 2 : 1, njx = pw.XS > 256 ? 2 : 1;
       // whole channel rows per wave (WCH) where an instance exists for the row lengths: pieces of 64 lanes
       const int wjd = hpvg_cdiv(pw.DS, 64), wjx = hpvg_cdiv(pw.XS, 64);
+      // 16-byte form: pieces of 64 groups
+      const int gjd = hpvg_cdiv(pw.Th * (pw.Tw / 4), 64), gjx = hpvg_cdiv((pw.Th + 2) * (pw.Tw / 4 + 2), 64);
       static const int wch_mode = [] { const char* e = getenv("HPVG_WGRADW_WCH"); return e ? atoi(e) : 1; }();
-#define HPVG_WW_LAUNCH(K, D, X, C)                                                                                     \
+#define HPVG_WW_LAUNCH(K, D, X, C, G)                                                                                  \
   {                                                                                                                    \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X, C>),                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X, C, G>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
         (void)hipGetLastError();                                                                                       \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X, C>), grid, dim3(256), pw.lds, s, a);                               \
+    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X, C, G>), grid, dim3(256), pw.lds, s, a);                            \
   }
 #define HPVG_WW_WCH(K)                                                                                                 \
-  if (wch_mode && wjd == 1 && wjx == 2) HPVG_WW_LAUNCH(K, 1, 2, true)                                                  \
-  else if (wch_mode && wjd == 1 && wjx == 3) HPVG_WW_LAUNCH(K, 1, 3, true)                                             \
-  else if (wch_mode && wjd == 2 && wjx == 3) HPVG_WW_LAUNCH(K, 2, 3, true)                                             \
-  else if (wch_mode && wjd == 2 && wjx == 4) HPVG_WW_LAUNCH(K, 2, 4, true)                                             \
-  else if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(K, 1, 1, false)                                                        \
-  else if (njd == 1) HPVG_WW_LAUNCH(K, 1, 2, false)                                                                    \
-  else HPVG_WW_LAUNCH(K, 2, 2, false)
+  if (pw.g16 && gjd == 1 && gjx == 1) HPVG_WW_LAUNCH(K, 1, 1, true, true)                                              \
+  else if (pw.g16 && gjd == 1) HPVG_WW_LAUNCH(K, 1, 2, true, true)                                                     \
+  else if (pw.g16) HPVG_WW_LAUNCH(K, 2, 2, true, true)                                                                 \
+  else if (wch_mode && wjd == 1 && wjx == 2) HPVG_WW_LAUNCH(K, 1, 2, true, false)                                      \
+  else if (wch_mode && wjd == 1 && wjx == 3) HPVG_WW_LAUNCH(K, 1, 3, true, false)                                      \
+  else if (wch_mode && wjd == 2 && wjx == 3) HPVG_WW_LAUNCH(K, 2, 3, true, false)                                      \
+  else if (wch_mode && wjd == 2 && wjx == 4) HPVG_WW_LAUNCH(K, 2, 4, true, false)                                      \
+  else if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(K, 1, 1, false, false)                                                \
+  else if (njd == 1) HPVG_WW_LAUNCH(K, 1, 2, false, false)                                                             \
+  else HPVG_WW_LAUNCH(K, 2, 2, false, false)
       if (KT == 3) {
         HPVG_WW_WCH(3)
       } else {
@@ -1576,12 +1632,24 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
   return hpvg_launch_status();
 }
 
-// Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer; a
-// negative mode only queries.  Returns the mode in force.
+// Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer, 3 = every
+// wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
+// HPVG_WGRADW_G16=0); a negative mode only queries.  Returns the mode in force.
 int hpvg_conv_bwd_weight_wino_config(int mode) {
-  (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the default
-  if (mode >= 0) g_wgradw_mode = mode > 2 ? 2 : mode;
-  return g_wgradw_mode;
+  (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the defaults
+  (void)plan_wgradw16_search(1, 8, 8, 1, 1, 1, 1);
+  static const int env_g16 = g_wgradw_g16;
+  static int four_byte_only = 0;
+  if (mode >= 0) {
+    four_byte_only = mode >= 3;
+    g_wgradw_mode = mode > 2 ? 2 : mode;
+    const int g16 = mode >= 3 ? 0 : env_g16;
+    if (g16 != g_wgradw_g16) {
+      g_wgradw_g16 = g16;
+      ++g_wgradw_gen;
+    }
+  }
+  return g_wgradw_mode == 2 && four_byte_only ? 3 : g_wgradw_mode;
 }
 
 // host only: the tile plan of the Winograd weight-gradient kernel: out[0..9] as hpvg_conv_bwd_weight_plan

@@ -32,10 +32,21 @@ typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
 // wave and tile, about half of their lanes idle).  WCH = true: wave w stages the WHOLE rows of channels w, w + 4, ... in
 // NJD + NJX pieces of 64 lanes (16 x (NJD + NJX) pieces per wave and tile, one behind each MFMA from the second one of a K
 // step on, two channels per step when they fit), so the pieces are fewer and the last of them is issued earlier in the K loop
+// one LDS-DMA piece (the builtin wants a literal size)
+#define WGW_PIECE(SRC, DST)                                                                      \
+  {                                                                                              \
+    if constexpr (G16) __builtin_amdgcn_global_load_lds((gptr_t)(SRC), (lptr_t)(DST), 16, 0, 0); \
+    else __builtin_amdgcn_global_load_lds((gptr_t)(SRC), (lptr_t)(DST), 4, 0, 0);                \
+  }
 #ifndef HPVG_WCH_SPREAD
 #define HPVG_WCH_SPREAD 1
 #endif
-template <int KT, int NJD, int NJX, bool WCH>
+// G16 (with WCH; W, the band width and the band origins multiples of 4): the rows are staged in 16-byte pieces - lane =
+// (tile row, group of four columns), a dY row of Tw floats (no junk columns: the K loop walks rows x Tw / 4 steps), an X row
+// of Tw + 8 floats from column w0 - 4 on, so that every group lies wholly inside the image or wholly outside (zero source);
+// the X rows sit one float into their channel row so that the operand pairs (first column w0 + ww - 1) stay 8-byte aligned.
+// Two or three pieces per channel row instead of five.
+template <int KT, int NJD, int NJX, bool WCH, bool G16>
 __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -45,6 +56,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   const int oblk = wave >> 1, cblk = wave & 1;
   constexpr int NCH = WCH ? 16 : 64;          // staging calls per tile and wave
   constexpr int LW = WCH ? 64 : 256;          // lanes that share a channel row
+  constexpr int PW = G16 ? 256 : LW;          // floats of LDS per piece
+  static_assert(!G16 || WCH, "G16 stages whole rows per wave");
   constexpr int NP = NJD + NJX;
   const int lid = WCH ? lane : tid;
   // workgroup ids as in conv_wgrad_kernel: time tap fastest, then the persistent slot; the outer taps get S0 <= S slots
@@ -96,10 +109,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   const char* xptr[NJX];
   unsigned dstr[NJD], xstr[NJX];
   bool dln[NJD], xln[NJX];
+  const int gpr = a.Tw >> 2, gprx = gpr + 2;          // G16: 16-byte groups per dY / X row
 #pragma unroll
-  for (int j = 0; j < NJD; ++j) dln[j] = j * LW + lid < DS;
+  for (int j = 0; j < NJD; ++j) dln[j] = j * LW + lid < (G16 ? a.Th * gpr : DS);
 #pragma unroll
-  for (int j = 0; j < NJX; ++j) xln[j] = j * LW + lid < XS;
+  for (int j = 0; j < NJX; ++j) xln[j] = j * LW + lid < (G16 ? (a.Th + 2) * gprx : XS);
   const unsigned cbytes = (unsigned)(cstride * 4) * (WCH ? 4u : 1u);   // to the next channel this wave stages
   auto setup = [&](int tile) {
     const int t = tile % a.T;  // time-major tile order
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
 #pragma unroll
     for (int j = 0; j < NJD; ++j) {
       const int p = j * LW + lid;
-      const int hh = p / RS, ww = p - hh * RS;
+      const int hh = G16 ? p / gpr : p / RS, ww = G16 ? 4 * (p - hh * gpr) : p - hh * RS;
       const int gh = h0 + hh, gw = w0 + ww;
       const bool ok = hh < a.Th && ww < a.Tw && gh < a.H && gw < a.W;
       dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
 #pragma unroll
     for (int j = 0; j < NJX; ++j) {
       const int p = j * LW + lid;
-      const int hh = p / RS, ww = p - hh * RS;
+      const int hh = G16 ? p / gprx : p / RS, ww = G16 ? 4 * (p - hh * gprx) - 3 : p - hh * RS;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
       const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
       xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   float* dma_x = lds;
   auto dma_begin = [&](float* buf) {
     dma_d = buf + (WCH ? wave * DS : wave * 64);
-    dma_x = buf + 64 * DS + (WCH ? wave * XS : wave * 64);
+    dma_x = buf + 64 * DS + (WCH ? wave * XS : wave * 64) + (G16 ? 1 : 0);
   };
   // (the two halves of a channel are issued behind DIFFERENT MFMAs of the K loop: an LDS-DMA instruction holds the issue port
   // for about one MFMA's duration, and with one wave per SIMD whatever does not fit an MFMA's shadow stalls the matrix pipe)
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     if ((WCH ? 4 * c + wave : c) < no) {
 #pragma unroll
       for (int j = 0; j < NJD; ++j) {
-        if (dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * LW), 4, 0, 0);
+        if (dln[j]) WGW_PIECE(dptr[j], dma_d + j * PW);
         dptr[j] += dstr[j];
       }
     }
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     if ((WCH ? 4 * c + wave : c) < nc) {
 #pragma unroll
       for (int j = 0; j < NJX; ++j) {
-        if (xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * LW), 4, 0, 0);
+        if (xln[j]) WGW_PIECE(xptr[j], dma_x + j * PW);
         xptr[j] += xstr[j];
       }
     }
@@ -173,13 +187,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
 #pragma unroll
       for (int j = 0; j < NJD; ++j)
         if (q == j) {
-          if (ch < no && dln[j]) __builtin_amdgcn_global_load_lds((gptr_t)dptr[j], (lptr_t)(dma_d + j * LW), 4, 0, 0);
+          if (ch < no && dln[j]) WGW_PIECE(dptr[j], dma_d + j * PW);
           dptr[j] += dstr[j];
         }
 #pragma unroll
       for (int j = 0; j < NJX; ++j)
         if (q == NJD + j) {
-          if (ch < nc && xln[j]) __builtin_amdgcn_global_load_lds((gptr_t)xptr[j], (lptr_t)(dma_x + j * LW), 4, 0, 0);
+          if (ch < nc && xln[j]) WGW_PIECE(xptr[j], dma_x + j * PW);
           xptr[j] += xstr[j];
         }
       if (q == NP - 1) {
@@ -215,16 +229,23 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     if (active && tt_cur >= 0 && tt_cur < a.T) {
       // this lane's pair of step st: positions 4 st + 2 half, + 1
       const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
-      const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half;
+      const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half + (G16 ? 1 : 0);
+      // G16: X offset of the step being loaded (row r, step wc of the row: r * RS + 4 * wc + 3; steps are loaded in order)
+      int xo = 3, wc = 0;
       // two register sets: the LDS reads of step st+1 are issued before the MFMAs of step st
       wf32x2a pa, pb0[3], pb1[3], qa, qb0[3], qb1[3];
 #define WW_LOAD(A, B0, B1, ST)                                                           \
   {                                                                                      \
     const int q0_ = (ST) * 4;                                                            \
+    const int x0_ = G16 ? xo : q0_;                                                      \
     A = *reinterpret_cast<const wf32x2a*>(dl + q0_);                                     \
     _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                   \
-      B0[dh] = *reinterpret_cast<const wf32x2a*>(xl + q0_ + dh * RS);                    \
-      B1[dh] = *reinterpret_cast<const wf32x2a*>(xl + q0_ + dh * RS + 2);                \
+      B0[dh] = *reinterpret_cast<const wf32x2a*>(xl + x0_ + dh * RS);                    \
+      B1[dh] = *reinterpret_cast<const wf32x2a*>(xl + x0_ + dh * RS + 2);                \
+    }                                                                                    \
+    if (G16) {                                                                           \
+      xo += 4;                                                                           \
+      if (++wc == gpr) { wc = 0; xo += 8; }                                              \
     }                                                                                    \
   }
 // 12 MFMAs with three channels of DMA staging between them (the rate per position of conv_wgrad_kernel): a channel's dY

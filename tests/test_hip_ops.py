@@ -226,6 +226,10 @@ def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, win
     (2, 64, 64, (3, 5, 6)), (1, 64, 64, (4, 18, 33)), (1, 64, 128, (2, 5, 4)), (1, 128, 70, (3, 30, 50)), (1, 16, 24, (3, 4, 7)),
     (1, 8, 8, (1, 1, 1)), (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (1, 5, 70, (2, 3, 300)),
     (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),
+    # widths that are multiples of 4: the 16-byte staging form (bands cut ragged, one band, rows past the image, channel
+    # blocks that are not full, several pieces per row) - mode 3 runs the 4-byte form on the same inputs
+    (1, 64, 64, (3, 7, 8)), (2, 64, 64, (2, 9, 36)), (1, 70, 130, (2, 5, 52)), (1, 64, 64, (2, 20, 204)), (2, 64, 64, (31, 256)),
+    (1, 24, 40, (3, 3, 4)), (1, 64, 64, (1, 50, 100)),
 ])
 def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(ops, B, Cin, Cout, sp):
     """conv_wgradw_kernel (transposed F(2,3) along W, output transform in its reduce kernel; forced for every wide layer)
@@ -245,7 +249,7 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     try:
         want_db = gy.sum(dim=[0] + list(range(2, 2 + nd)))
         bbase = _rand(Cout, seed=35).to(DEV)
-        for mode in (2, 0):
+        for mode in (2, 3, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
@@ -254,7 +258,7 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
             # weight AND bias gradient from one launch (the Winograd kernel's centre-tap workgroups sum dY on the side)
             accw, accb = base.clone(), bbase.clone()
             fused = ops.conv_bwd_weight_bias_raw(gyd, xd, w.shape, accw, accb)
-            assert fused == (mode == 2 and Cin > 4 and Cout > 4)
+            assert fused == (mode >= 2 and Cin > 4 and Cout > 4)
             if fused:
                 assert_close(accw - base, want, RTOL, "wino.fused.dw", atol=1e-5 * float(base.abs().max()))
                 assert_close(accb - bbase, want_db, 1e-5, "wino.fused.db", atol=2e-6 * float(bbase.abs().max()))
@@ -262,10 +266,11 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     finally:
         lib.hpvg_conv_bwd_weight_wino_config(prev)
     for mode, (dw, acc) in res.items():
-        tag = "wino." if mode == 2 else "direct."
+        tag = {2: "wino.", 3: "wino4.", 0: "direct."}[mode]
         assert_close(dw, want, RTOL, tag + "dw")
         assert_close(acc - base, want, RTOL, tag + "dw.accumulate", atol=1e-5 * float(base.abs().max()))
     assert_close(res[2][0], res[0][0], 3e-5, "wino-vs-direct.dw")
+    assert_close(res[3][0], res[0][0], 3e-5, "wino4-vs-direct.dw")
 
 
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])

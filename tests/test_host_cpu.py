@@ -94,18 +94,31 @@ def test_winograd_weight_gradient_plan_geometry():
     half-wave's 32 channel rows in 32 different bank pairs), every read of the K loop inside its row, two buffers in LDS."""
     lib = hplib.load()
     out = (ctypes.c_int * 10)()
-    for KT, T in ((3, 5), (1, 1)):
-        for H in (1, 2, 9, 45, 144):
-            for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 230, 255, 256, 300]:
-                assert lib.hpvg_conv_bwd_weight_wino_plan(2, 64, 64, T, H, W, KT, out) == 0, (KT, H, W)
-                Th, Tw, nth, ntw, QK, S, DS, XS, lds, ntiles = list(out)
-                RS = Tw + 2
-                assert Tw % 2 == 0 and QK % 4 == 0 and QK >= Th * RS and DS % 4 == 2 and XS % 4 == 2
-                assert ntw * Tw >= W and (ntw - 1) * Tw < W and nth * Th >= H and (nth - 1) * Th < H
-                assert DS >= QK and XS >= QK + 2 * RS + 2 and XS >= (Th + 2) * RS      # furthest read: QK - 2 + 2*RS + 3
-                assert lds == 2 * 64 * (DS + XS) * 4 and lds <= 160 * 1024 and DS <= 512 and XS <= 512
-                assert ntiles == 2 * T * nth * ntw and 1 <= S <= 256
-                assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", 2, 64, 64, T, H, W, KT) >= 256 + S * KT * 12 * 4096 * 4
+    prev = lib.hpvg_conv_bwd_weight_wino_config(-1)
+    try:
+        for mode in (2, 3):     # 3: the 4-byte staging form for every width
+            assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
+            for KT, T in ((3, 5), (1, 1)):
+                for H in (1, 2, 9, 45, 144):
+                    for W in list(range(1, 70)) + [81, 129, 130, 146, 183, 204, 230, 255, 256, 300]:
+                        assert lib.hpvg_conv_bwd_weight_wino_plan(2, 64, 64, T, H, W, KT, out) == 0, (KT, H, W)
+                        Th, Tw, nth, ntw, QK, S, DS, XS, lds, ntiles = list(out)
+                        assert ntw * Tw >= W and (ntw - 1) * Tw < W and nth * Th >= H and (nth - 1) * Th < H
+                        assert DS % 4 == 2 and XS % 4 == 2
+                        assert lds == 2 * 64 * (DS + XS) * 4 and lds <= 160 * 1024 and DS <= 512 and XS <= 512
+                        assert ntiles == 2 * T * nth * ntw and 1 <= S <= 256
+                        assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", 2, 64, 64, T, H, W, KT) >= 256 + S * KT * 12 * 4096 * 4
+                        if mode == 2 and W % 4 == 0:
+                            # 16-byte form: dY rows of Tw floats, X rows of Tw + 8 from column w0 - 4, one float into the
+                            # channel row; at most two 64-lane pieces per row and operand
+                            assert Tw % 4 == 0 and QK == Th * Tw and DS == QK + 2 and XS == (Th + 2) * (Tw + 8) + 2
+                            assert Th * (Tw // 4) <= 128 and (Th + 2) * (Tw // 4 + 2) <= 128
+                        else:
+                            RS = Tw + 2
+                            assert Tw % 2 == 0 and QK % 4 == 0 and QK >= Th * RS
+                            assert DS >= QK and XS >= QK + 2 * RS + 2 and XS >= (Th + 2) * RS  # furthest read: QK - 2 + 2*RS + 3
+    finally:
+        lib.hpvg_conv_bwd_weight_wino_config(prev)
 
 
 def test_tables_match_reference():
