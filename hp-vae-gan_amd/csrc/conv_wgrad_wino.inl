@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       cnext = 0;
     }
     const int tt_cur = tile % a.T + dt - pt;
+#ifdef HPVG_ABLW_NOMMA
+    if (false) {   // development ablation (timing only): everything but the K loop
+#else
     if (active && tt_cur >= 0 && tt_cur < a.T) {
+#endif
       // this lane's pair of step st: positions 4 st + 2 half, + 1
       const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
       const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half + (G16 ? 1 : 0);
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       bsum = 0.f;
     }
     while (cnext < NCH) { dma_channel(cnext); ++cnext; }  // whatever did not fit into the K loop (short loops, idle waves)
+#ifndef HPVG_ABLW_NOBAR   // (development ablation, timing only: no barrier between tiles)
     __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
+#endif
     cur ^= 1;
   }
 
