@@ -221,7 +221,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     float* bufc = lds + cur * BUF;
     cnext = NCH;
     if (have_next) {
+#ifdef HPVG_ABLW_NOSETUP   // (development ablation, timing only: every tile stages the first one again, the set-up hoisted)
+      setup(slot);
+#else
       setup(next);
+#endif
       dma_begin(lds + (cur ^ 1) * BUF);
       cnext = 0;
     }
