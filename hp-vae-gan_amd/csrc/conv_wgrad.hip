@@ -1173,12 +1173,15 @@ WPlan plan_wgradw_search(int B, int Cin, int Cout, int T, int H, int W, int KT) 
 // the 16-byte staging form (conv_wgradw_kernel<.., G16>): W a multiple of 4, bands of a multiple of 4 columns, dY rows of Tw
 // floats, X rows of Tw + 8 from column w0 - 4; at most two 64-lane pieces per channel row and operand
 int g_wgradw_g16 = -1;
+int g_wgradw_w8 = -1;   // eight-wave form of the 16-byte kernel (HPVG_WGRADW_W8, hpvg_conv_bwd_weight_wino_config mode 4 = off)
 int g_wgradw_gen = 0;   // bumped when hpvg_conv_bwd_weight_wino_config changes what the planner may pick: drops the plan caches
 WPlan plan_wgradw16_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   WPlan best{};
   if (g_wgradw_g16 < 0) {
     const char* e = getenv("HPVG_WGRADW_G16");
     g_wgradw_g16 = e ? atoi(e) : 1;
+    const char* e8 = getenv("HPVG_WGRADW_W8");
+    g_wgradw_w8 = e8 ? atoi(e8) : 1;
   }
   if (W % 4 != 0 || !g_wgradw_g16) return best;
   double best_cost = 1e300;
@@ -1495,28 +1498,33 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       // 16-byte form: pieces of 64 groups
       const int gjd = hpvg_cdiv(pw.Th * (pw.Tw / 4), 64), gjx = hpvg_cdiv((pw.Th + 2) * (pw.Tw / 4 + 2), 64);
       static const int wch_mode = [] { const char* e = getenv("HPVG_WGRADW_WCH"); return e ? atoi(e) : 1; }();
-#define HPVG_WW_LAUNCH(K, D, X, C, G)                                                                                  \
+#define HPVG_WW_LAUNCH(K, D, X, C, G, E)                                                                               \
   {                                                                                                                    \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X, C, G>),                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw_kernel<K, D, X, C, G, E>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
         (void)hipGetLastError();                                                                                       \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X, C, G>), grid, dim3(256), pw.lds, s, a);                            \
+    hipLaunchKernelGGL((conv_wgradw_kernel<K, D, X, C, G, E>), grid, dim3(E ? 512 : 256), pw.lds, s, a);               \
   }
+      // eight waves (two per SIMD, half of the Winograd points each) for the whole-row staging forms: HPVG_WGRADW_W8=0 keeps four
+      const int w8_mode = g_wgradw_w8;
 #define HPVG_WW_WCH(K)                                                                                                 \
-  if (pw.g16 && gjd == 1 && gjx == 1) HPVG_WW_LAUNCH(K, 1, 1, true, true)                                              \
-  else if (pw.g16 && gjd == 1) HPVG_WW_LAUNCH(K, 1, 2, true, true)                                                     \
-  else if (pw.g16) HPVG_WW_LAUNCH(K, 2, 2, true, true)                                                                 \
-  else if (wch_mode && wjd == 1 && wjx == 2) HPVG_WW_LAUNCH(K, 1, 2, true, false)                                      \
-  else if (wch_mode && wjd == 1 && wjx == 3) HPVG_WW_LAUNCH(K, 1, 3, true, false)                                      \
-  else if (wch_mode && wjd == 2 && wjx == 3) HPVG_WW_LAUNCH(K, 2, 3, true, false)                                      \
-  else if (wch_mode && wjd == 2 && wjx == 4) HPVG_WW_LAUNCH(K, 2, 4, true, false)                                      \
-  else if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(K, 1, 1, false, false)                                                \
-  else if (njd == 1) HPVG_WW_LAUNCH(K, 1, 2, false, false)                                                             \
-  else HPVG_WW_LAUNCH(K, 2, 2, false, false)
+  if (pw.g16 && gjd == 1 && gjx == 1 && w8_mode) HPVG_WW_LAUNCH(K, 1, 1, true, true, true)                             \
+  else if (pw.g16 && gjd == 1 && w8_mode) HPVG_WW_LAUNCH(K, 1, 2, true, true, true)                                    \
+  else if (pw.g16 && w8_mode) HPVG_WW_LAUNCH(K, 2, 2, true, true, true)                                                \
+  else if (pw.g16 && gjd == 1 && gjx == 1) HPVG_WW_LAUNCH(K, 1, 1, true, true, false)                                  \
+  else if (pw.g16 && gjd == 1) HPVG_WW_LAUNCH(K, 1, 2, true, true, false)                                              \
+  else if (pw.g16) HPVG_WW_LAUNCH(K, 2, 2, true, true, false)                                                          \
+  else if (wch_mode && wjd == 1 && wjx == 2) HPVG_WW_LAUNCH(K, 1, 2, true, false, false)                               \
+  else if (wch_mode && wjd == 1 && wjx == 3) HPVG_WW_LAUNCH(K, 1, 3, true, false, false)                               \
+  else if (wch_mode && wjd == 2 && wjx == 3) HPVG_WW_LAUNCH(K, 2, 3, true, false, false)                               \
+  else if (wch_mode && wjd == 2 && wjx == 4) HPVG_WW_LAUNCH(K, 2, 4, true, false, false)                               \
+  else if (njd == 1 && njx == 1) HPVG_WW_LAUNCH(K, 1, 1, false, false, false)                                          \
+  else if (njd == 1) HPVG_WW_LAUNCH(K, 1, 2, false, false, false)                                                      \
+  else HPVG_WW_LAUNCH(K, 2, 2, false, false, false)
       if (KT == 3) {
         HPVG_WW_WCH(3)
       } else {
@@ -1634,22 +1642,25 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
 
 // Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer, 3 = every
 // wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
-// HPVG_WGRADW_G16=0); a negative mode only queries.  Returns the mode in force.
+// HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; a negative mode only queries.
+// Returns the mode in force.
 int hpvg_conv_bwd_weight_wino_config(int mode) {
   (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the defaults
   (void)plan_wgradw16_search(1, 8, 8, 1, 1, 1, 1);
-  static const int env_g16 = g_wgradw_g16;
-  static int four_byte_only = 0;
+  static const int env_g16 = g_wgradw_g16, env_w8 = g_wgradw_w8;
+  static int four_byte_only = 0, four_waves = 0;
   if (mode >= 0) {
-    four_byte_only = mode >= 3;
+    four_byte_only = mode == 3;
+    four_waves = mode == 4;
+    g_wgradw_w8 = four_waves ? 0 : env_w8;
     g_wgradw_mode = mode > 2 ? 2 : mode;
-    const int g16 = mode >= 3 ? 0 : env_g16;
+    const int g16 = mode == 3 ? 0 : env_g16;
     if (g16 != g_wgradw_g16) {
       g_wgradw_g16 = g16;
       ++g_wgradw_gen;
     }
   }
-  return g_wgradw_mode == 2 && four_byte_only ? 3 : g_wgradw_mode;
+  return g_wgradw_mode == 2 && four_byte_only ? 3 : (g_wgradw_mode == 2 && four_waves ? 4 : g_wgradw_mode);
 }
 
 // host only: the tile plan of the Winograd weight-gradient kernel: out[0..9] as hpvg_conv_bwd_weight_plan

@@ -46,15 +46,25 @@ typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
 // of Tw + 8 floats from column w0 - 4 on, so that every group lies wholly inside the image or wholly outside (zero source);
 // the X rows sit one float into their channel row so that the operand pairs (first column w0 + ww - 1) stay 8-byte aligned.
 // Two or three pieces per channel row instead of five.
-template <int KT, int NJD, int NJX, bool WCH, bool G16>
-__global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) {
+// W8 (with WCH): EIGHT waves, two per SIMD - waves w and w + 4 own the same 32 x 32 (o, c) sub-block and two of the four
+// Winograd points each (six accumulator tiles, six MFMAs per K step and wave, selected by coefficients: no divergent code),
+// so that one wave's LDS reads, transforms and staging pieces run under the other's MFMAs (with one wave per SIMD nothing
+// hides them); each wave stages the rows of eight channels.  Worth 2.5 % with the 16-byte form (stages 8, 9), a loss with
+// the 4-byte WCH form (more pieces per wave pair): instantiated for G16 only.  (hipcc reads a patch row as ds_read2_b64;
+// forcing two ds_read_b64 - the 64-bank path - is 1 % slower here as well.)
+template <int KT, int NJD, int NJX, bool WCH, bool G16, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wgradw_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NW = W8 ? 8 : 4;              // waves
+  constexpr int NT = NW * 64;
+  static_assert(!W8 || WCH, "W8 stages whole rows per wave");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int oblk = wave >> 1, cblk = wave & 1;
-  constexpr int NCH = WCH ? 16 : 64;          // staging calls per tile and wave
+  const int w4 = wave & 3, jh = wave >> 2;    // sub-block, half of the points (W8)
+  const int oblk = w4 >> 1, cblk = w4 & 1;
+  constexpr int NCH = WCH ? 64 / NW : 64;     // staging calls per tile and wave
   constexpr int LW = WCH ? 64 : 256;          // lanes that share a channel row
   constexpr int PW = G16 ? 256 : LW;          // floats of LDS per piece
   static_assert(!G16 || WCH, "G16 stages whole rows per wave");
@@ -88,20 +98,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   const int pt = (KT == 3 ? 1 : 0);
   const int ntiles = a.B * a.T * a.nth * a.ntw;
 
-  f32x16 acc[12];   // [dh][j]
+  constexpr int JN = W8 ? 2 : 4;              // points per wave
+  constexpr int NACC = 3 * JN;
+  f32x16 acc[NACC];   // [dh][j]
 #pragma unroll
-  for (int k = 0; k < 12; ++k)
+  for (int k = 0; k < NACC; ++k)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
   // Bias gradient on the side (a.bpart): db[o] = sum of dY[o] over batch and positions.  The centre-tap workgroups walk every
   // tile, and the waves of their first input-channel half hold y0 + y1 of every dY pair of their 32 output channels (the
   // Winograd Y_1): one more add per K step.  Per tile in fp32, tiles added with Kahan compensation (a lane sums thousands
   // of values), slots summed in double by the reduce kernel.
-  const float bflag = (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) ? 1.f : 0.f;
+  const float bflag = (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0 && jh == 0) ? 1.f : 0.f;
   float bsum = 0.f, brun = 0.f, bcomp = 0.f;
 
   // zero both buffers once: rows of absent channels are never written afterwards
-  for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
+  for (int i = tid; i < 2 * BUF; i += NT) lds[i] = 0.f;
 
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   for (int j = 0; j < NJD; ++j) dln[j] = j * LW + lid < (G16 ? a.Th * gpr : DS);
 #pragma unroll
   for (int j = 0; j < NJX; ++j) xln[j] = j * LW + lid < (G16 ? (a.Th + 2) * gprx : XS);
-  const unsigned cbytes = (unsigned)(cstride * 4) * (WCH ? 4u : 1u);   // to the next channel this wave stages
+  const unsigned cbytes = (unsigned)(cstride * 4) * (WCH ? (unsigned)NW : 1u);   // to the next channel this wave stages
   auto setup = [&](int tile) {
     const int t = tile % a.T;  // time-major tile order
     int r = tile / a.T;
@@ -156,24 +168,24 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   // (the two halves of a channel are issued behind DIFFERENT MFMAs of the K loop: an LDS-DMA instruction holds the issue port
   // for about one MFMA's duration, and with one wave per SIMD whatever does not fit an MFMA's shadow stalls the matrix pipe)
   auto dma_dy = [&](int c) {
-    if ((WCH ? 4 * c + wave : c) < no) {
+    if ((WCH ? NW * c + wave : c) < no) {
 #pragma unroll
       for (int j = 0; j < NJD; ++j) {
         if (dln[j]) WGW_PIECE(dptr[j], dma_d + j * PW);
         dptr[j] += dstr[j];
       }
     }
-    dma_d += WCH ? 4 * DS : DS;
+    dma_d += WCH ? NW * DS : DS;
   };
   auto dma_xx = [&](int c) {
-    if ((WCH ? 4 * c + wave : c) < nc) {
+    if ((WCH ? NW * c + wave : c) < nc) {
 #pragma unroll
       for (int j = 0; j < NJX; ++j) {
         if (xln[j]) WGW_PIECE(xptr[j], dma_x + j * PW);
         xptr[j] += xstr[j];
       }
     }
-    dma_x += WCH ? 4 * XS : XS;
+    dma_x += WCH ? NW * XS : XS;
   };
   auto dma_channel = [&](int c) {
     dma_dy(c);
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   int cnext = NCH;                 // next staging call (NCH = nothing left)
   auto dma_piece = [&](int q) __attribute__((always_inline)) {
     if (cnext < NCH) {
-      const int ch = 4 * cnext + wave;
+      const int ch = NW * cnext + wave;
 #pragma unroll
       for (int j = 0; j < NJD; ++j)
         if (q == j) {
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
           xptr[j] += xstr[j];
         }
       if (q == NP - 1) {
-        dma_d += 4 * DS;
-        dma_x += 4 * XS;
+        dma_d += NW * DS;
+        dma_x += NW * XS;
         ++cnext;
       }
     }
@@ -290,17 +302,42 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
       WW_AFTER(dh * 4 + 3)                                                                                         \
     }                                                                                                              \
   }
-      int st = 0;
-      if (st < nsteps) WW_LOAD(pa, pb0, pb1, st);
-      for (; st + 1 < nsteps; st += 2) {
-        WW_LOAD(qa, qb0, qb1, st + 1);
-        WW_MMA(pa, pb0, pb1);
-        if (st + 2 < nsteps) WW_LOAD(pa, pb0, pb1, st + 2);
-        WW_MMA(qa, qb0, qb1);
-      }
-      if (st < nsteps) WW_MMA(pa, pb0, pb1);
+// W8: this wave's two points by coefficients (jh = 0: (y0, d0 - d2), (y0 + y1, d1 + d2); jh = 1: (y0 - y1, d2 - d1),
+// (-y1, d1 - d3); multiplications by 0 / 1 / -1 are exact)
+#define WW_MMA8(A, B0, B1)                                                                                         \
+  {                                                                                                                \
+    const float y0_ = A[0], y1_ = A[1];                                                                            \
+    const float a0_ = __builtin_fmaf(-sj, y1_, y0_);                                                               \
+    const float a1_ = __builtin_fmaf(c0j, y0_, c1j * y1_);                                                         \
+    bsum = __builtin_fmaf(bflag, a1_, bsum);                                                                       \
+    _Pragma("unroll") for (int dh = 0; dh < 3; ++dh) {                                                             \
+      const float d0_ = B0[dh][0], d1_ = B0[dh][1], d2_ = B1[dh][0], d3_ = B1[dh][1];                              \
+      const float b0_ = __builtin_fmaf(c0j, d0_, __builtin_fmaf(-sj, d1_, -c1j * d2_));                            \
+      const float b1_ = __builtin_fmaf(c0j, d2_, __builtin_fmaf(-sj, d3_, d1_));                                   \
+      acc[dh * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[dh * 2 + 0], 0, 0, 0);                  \
+      WW_AFTER(dh * 2 + 0)                                                                                         \
+      acc[dh * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[dh * 2 + 1], 0, 0, 0);                  \
+      WW_AFTER(dh * 2 + 1)                                                                                         \
+    }                                                                                                              \
+  }
+#define WW_KLOOP(MMA)                                                                    \
+  {                                                                                      \
+    int st = 0;                                                                          \
+    if (st < nsteps) WW_LOAD(pa, pb0, pb1, st);                                          \
+    for (; st + 1 < nsteps; st += 2) {                                                   \
+      WW_LOAD(qa, qb0, qb1, st + 1);                                                     \
+      MMA(pa, pb0, pb1);                                                                 \
+      if (st + 2 < nsteps) WW_LOAD(pa, pb0, pb1, st + 2);                                \
+      MMA(qa, qb0, qb1);                                                                 \
+    }                                                                                    \
+    if (st < nsteps) MMA(pa, pb0, pb1);                                                  \
+  }
+      const float sj = (float)jh, c0j = 1.f - sj, c1j = 1.f - 2.f * sj;
+      if constexpr (W8) WW_KLOOP(WW_MMA8) else WW_KLOOP(WW_MMA)
+#undef WW_KLOOP
 #undef WW_LOAD
 #undef WW_MMA
+#undef WW_MMA8
 #undef WW_AFTER
     }
     {   // this tile's bias sum into the running one (Kahan)
@@ -316,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
     cur ^= 1;
   }
 
-  if (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) {
+  if (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0 && jh == 0) {
     // the two half-waves hold the even / odd pairs of the same channels
     const float tot = brun + __shfl_xor(brun, 32, 64);
     if (half == 0) a.bpart[((long)slot * a.nob + ob) * 64 + oblk * 32 + l31] = active ? tot : 0.f;
@@ -324,11 +361,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw_kernel(const WgradArgs a) 
   // ---- partial slab: part[s][dt][z][dh*4 + j][o64][c64]
   float* pp = a.part + ((((long)slot * KT + dt) * nz + z) * 12) * 4096;
 #pragma unroll
-  for (int k = 0; k < 12; ++k)
+  for (int k = 0; k < NACC; ++k)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = oblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      pp[(long)k * 4096 + row * 64 + cblk * 32 + l31] = active ? acc[k][e] : 0.f;
+      const int kk = W8 ? (k >> 1) * 4 + 2 * jh + (k & 1) : k;     // tile (dh, point)
+      pp[(long)kk * 4096 + row * 64 + cblk * 32 + l31] = active ? acc[k][e] : 0.f;
     }
 }
 

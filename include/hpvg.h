@@ -96,7 +96,8 @@ int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int
 /* Wide layers (Cin > 4 and Cout > 4) have a Winograd weight-gradient kernel behind the same entry point (the transpose of
  * the forward F(2,3) along W: four products per pair of output columns and (dt, dh) instead of six, summed over all
  * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never, 1 = by size, 2 = every wide
- * layer, 3 = every wide layer without the 16-byte staging form (widths that are multiples of 4 otherwise get it);
+ * layer, 3 = every wide layer without the 16-byte staging form (widths that are multiples of 4 otherwise get it), 4 = every
+ * wide layer with the 16-byte form on four waves instead of eight;
  * negative = query.  Returns the mode in force.  Host only. */
 int hpvg_conv_bwd_weight_wino_config(int mode);
 /* The weight gradient and the conv's bias gradient db[o] (+)= sum_{b,positions} dy[b][o] from ONE launch, for the layers

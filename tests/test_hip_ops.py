@@ -227,7 +227,8 @@ def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, win
     (1, 8, 8, (1, 1, 1)), (1, 12, 64, (2, 7, 1)), (1, 64, 64, (2, 9, 130)), (2, 64, 64, (7, 72, 129)), (1, 5, 70, (2, 3, 300)),
     (2, 64, 64, (9, 10)), (2, 64, 64, (24, 33)), (1, 64, 128, (48, 65)), (2, 64, 64, (200, 300)),
     # widths that are multiples of 4: the 16-byte staging form (bands cut ragged, one band, rows past the image, channel
-    # blocks that are not full, several pieces per row) - mode 3 runs the 4-byte form on the same inputs
+    # blocks that are not full, several pieces per row) - mode 3 runs the 4-byte form on the same inputs, mode 4 the 16-byte
+    # form on four waves (mode 2: eight)
     (1, 64, 64, (3, 7, 8)), (2, 64, 64, (2, 9, 36)), (1, 70, 130, (2, 5, 52)), (1, 64, 64, (2, 20, 204)), (2, 64, 64, (31, 256)),
     (1, 24, 40, (3, 3, 4)), (1, 64, 64, (1, 50, 100)),
 ])
@@ -249,7 +250,7 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     try:
         want_db = gy.sum(dim=[0] + list(range(2, 2 + nd)))
         bbase = _rand(Cout, seed=35).to(DEV)
-        for mode in (2, 3, 0):
+        for mode in (2, 3, 4, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
@@ -266,11 +267,12 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     finally:
         lib.hpvg_conv_bwd_weight_wino_config(prev)
     for mode, (dw, acc) in res.items():
-        tag = {2: "wino.", 3: "wino4.", 0: "direct."}[mode]
+        tag = {2: "wino.", 3: "wino4.", 4: "wino16x4waves.", 0: "direct."}[mode]
         assert_close(dw, want, RTOL, tag + "dw")
         assert_close(acc - base, want, RTOL, tag + "dw.accumulate", atol=1e-5 * float(base.abs().max()))
     assert_close(res[2][0], res[0][0], 3e-5, "wino-vs-direct.dw")
     assert_close(res[3][0], res[0][0], 3e-5, "wino4-vs-direct.dw")
+    assert_close(res[4][0], res[0][0], 3e-5, "wino16x4waves-vs-direct.dw")
 
 
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
