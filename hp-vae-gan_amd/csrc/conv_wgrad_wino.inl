@@ -32,6 +32,7 @@ typedef float wf32x2a __attribute__((ext_vector_type(2), aligned(8)));
 // wave and tile, about half of their lanes idle).  WCH = true: wave w stages the WHOLE rows of channels w, w + 4, ... in
 // NJD + NJX pieces of 64 lanes (16 x (NJD + NJX) pieces per wave and tile, one behind each MFMA from the second one of a K
 // step on, two channels per step when they fit), so the pieces are fewer and the last of them is issued earlier in the K loop
+// (eight waves, two pieces per row: behind MFMAs 1 and 4 of the step's six - 1-2 % over 1 and 2)
 // one LDS-DMA piece (the builtin wants a literal size)
 #define WGW_PIECE(SRC, DST)                                                                      \
   {                                                                                              \
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wgradw_kernel(const Wg
     } else {                                                                                                       \
       if (HPVG_WCH_SPREAD == 0 && (M) >= 1 && (M) <= NP) WGW_ABL_PIECE((M) - 1)                                    \
       if (HPVG_WCH_SPREAD == 0 && 2 * NP <= 11 && (M) > NP && (M) <= 2 * NP) WGW_ABL_PIECE((M) - 1 - NP)           \
-      if (HPVG_WCH_SPREAD == 1 && (M) >= 1 && (M) <= NP) WGW_ABL_PIECE((M) - 1)                                    \
+      if (HPVG_WCH_SPREAD == 1 && !(W8 && NP == 2) && (M) >= 1 && (M) <= NP) WGW_ABL_PIECE((M) - 1)                \
+      if (HPVG_WCH_SPREAD == 1 && W8 && NP == 2 && ((M) == 1 || (M) == 4)) WGW_ABL_PIECE((M) / 3)                  \
       if (HPVG_WCH_SPREAD == 2 && ((M) & 1) == 1 && ((M) >> 1) < NP) WGW_ABL_PIECE((M) >> 1)                       \
       if (HPVG_WCH_SPREAD == 3 && ((M) % 3) == 1 && ((M) / 3) < NP) WGW_ABL_PIECE((M) / 3)                         \
     }                                                                                                              \
