@@ -733,6 +733,53 @@ def test_full_size_conv_family_properties(ops):
     assert_close(lhs, rhs, 1e-4, "fullsize.linearity")
 
 
+def test_full_size_weight_gradient_by_supports_and_kernels(ops):
+    """The weight gradient at the BASELINE configs[2] finest level (B=2, 64->64, 13 x 144 x 256), where the oracle takes minutes:
+      * a dY that is zero outside a small block gives the oracle's weight (and bias) gradient of the matching crop of X (+1 voxel
+        of context) - three supports: the near corner (zero padding on three sides), an interior block that straddles tile and
+        band borders, the far corner (the last 16-byte groups of the tensor);
+      * on dense inputs the Winograd kernel in each of its forms (16-byte staging on eight and on four waves, 4-byte staging)
+        agrees with the direct kernels element by element, and the fused bias gradient with a plain sum."""
+    from hp_vae_gan_amd import lib as hplib
+    lib = hplib.load()
+    B, C, T, H, W = 2, 64, 13, 144, 256
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+    wshape = (C, C, 3, 3, 3)
+    prev = lib.hpvg_conv_bwd_weight_wino_config(-1)
+    try:
+        assert lib.hpvg_conv_bwd_weight_wino_config(2) == 2
+        for (t0, t1, h0, h1, w0, w1) in [(0, 2, 0, 5, 0, 7), (5, 8, 68, 75, 125, 135), (11, 13, 139, 144, 249, 256)]:
+            dy = torch.zeros(B, C, T, H, W, device=DEV)
+            blk = torch.randn(C, t1 - t0, h1 - h0, w1 - w0, device=DEV, generator=g)
+            dy[1, :, t0:t1, h0:h1, w0:w1] = blk
+            dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
+            assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
+            ts, hs, ws_ = max(t0 - 1, 0), max(h0 - 1, 0), max(w0 - 1, 0)
+            te, he, we = min(t1 + 1, T), min(h1 + 1, H), min(w1 + 1, W)
+            xc = x[1:2, :, ts:te, hs:he, ws_:we].cpu()
+            dyc = torch.zeros(1, C, te - ts, he - hs, we - ws_)
+            dyc[0, :, t0 - ts:t1 - ts, h0 - hs:h1 - hs, w0 - ws_:w1 - ws_] = blk.cpu()
+            wz = torch.zeros(wshape, requires_grad=True)
+            (want,) = torch.autograd.grad(O.conv(xc, wz, None), wz, dyc)
+            assert_close(dw, want, RTOL, "fullsize.wgrad.support(%d,%d,%d)" % (t0, h0, w0))
+            assert_close(db, blk.cpu().sum(dim=(1, 2, 3)), 1e-5, "fullsize.bgrad.support(%d,%d,%d)" % (t0, h0, w0))
+        dy = torch.randn(B, C, T, H, W, device=DEV, generator=g)
+        res = {}
+        for mode in (2, 4, 3, 0):
+            assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
+            res[mode] = ops.conv_bwd_weight_raw(dy, x, wshape)
+        for mode in (2, 4, 3):
+            assert_close(res[mode], res[0], 3e-5, "fullsize.wgrad.mode%d-vs-direct" % mode)
+        assert lib.hpvg_conv_bwd_weight_wino_config(2) == 2
+        dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
+        assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
+        assert torch.equal(dw, res[2])
+        assert_close(db, dy.double().sum(dim=(0, 2, 3, 4)).float(), 1e-5, "fullsize.bgrad", atol=2e-2)
+    finally:
+        lib.hpvg_conv_bwd_weight_wino_config(prev)
+
+
 def test_full_size_batchnorm_properties(ops):
     """Finest-level BatchNorm + LeakyReLU (B=2, 64 ch, 13 x 144 x 256): before the activation the output has per-channel
     mean beta and variance gamma^2 (eps-corrected), whatever the input; dbeta / dgamma equal the direct sums."""
