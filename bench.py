@@ -27,18 +27,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0
 
 
-def measured_traffic(shape):
-    """HBM bytes per launch of the dominant kernel at `shape`, from the rocprofv3 PMC passes committed under profiles/
+def measured_traffic(family, shape):
+    """HBM bytes per launch of a roofline kernel family at `shape`, from the rocprofv3 PMC passes committed under profiles/
     (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, gfx950 x2 fetch correction: tools/pmc_summary.py writes
-    profiles/roofline_traffic.json beside the per-kernel csv).  bench.py cannot run the profiler itself; a shape the
-    profile does not cover yields None."""
+    profiles/roofline_traffic.json beside the per-kernel csv).  bench.py cannot run the profiler itself; a (family, shape)
+    the profile does not cover yields None."""
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             rec = json.load(f)
     except (OSError, ValueError):
         return None, None
     for e in rec.get("entries", []):
-        if tuple(e["shape"]) == tuple(shape):
+        if e.get("family", "conv_fwd") == family and tuple(e["shape"]) == tuple(shape):
             return e["bytes"], e["source"]
     return None, None
 
@@ -152,15 +152,11 @@ def build_gpu_stages(device, stages):
     return out, shapes
 
 
-# iteration GFLOP per stage of configs[2] as the reference executes it: the extrapolation rule for the
-# stages the CPU leg does not run
-REF_ITER_GFLOP = {0: 41, 1: 67, 2: 105, 3: 615, 4: 1081, 5: 1838, 6: 3925, 7: 6602, 8: 10805, 9: 27914}
-
-
 def cpu_iters(s):
-    """timed iterations of the CPU leg at stage s (after one warm-up): BASELINE.md section 4's plan within the bench's time
-    budget (~30 s of CPU work on the box's 16 threads)"""
-    return 20 if s <= 3 else (3 if s <= 5 else 1)
+    """timed iterations of the CPU leg at stage s (after one warm-up iteration): BASELINE.md section 4's plan - every stage of
+    the sweep is RUN (no extrapolation): 20 iterations at stages 0-3, 3 at 4-7, 1 at 8-9 (~3 minutes on the box's 16 threads,
+    most of it the two finest stages)"""
+    return 20 if s <= 3 else (3 if s <= 7 else 1)
 
 
 def cpu_baseline(stages, threads):
@@ -249,6 +245,115 @@ def _parallelism(world):
             "slabs); %s; earlier GAN stages: 2 ranks (8 working ranks of %d)" % (omin, quad[len(vae):], world)).join([vae, ""])
 
 
+def comm_check(world, rank, device, backend, dev_index):
+    """Proof, in the JSON line, of what the run's communicator was: one all_reduce of ones over the process group the
+    schedules use (RCCL when backend == "nccl") must count `world` ranks, and every rank reports the device it sits on.
+    N = 1: no communicator."""
+    if world == 1:
+        return {"backend": None, "ranks": 1, "devices": [dev_index], "distinct_devices": 1}
+    one = torch.ones(1, device=device if backend == "nccl" else "cpu", dtype=torch.float32)
+    dist.all_reduce(one)
+    ranks = int(round(float(one.item())))
+    devs = [None] * world
+    name = torch.cuda.get_device_properties(dev_index).name if torch.cuda.is_available() else "cpu"
+    dist.all_gather_object(devs, (rank, dev_index, name))
+    devs.sort()
+    if ranks != world:
+        raise RuntimeError("the %s communicator counted %d ranks, the launch has %d" % (backend, ranks, world))
+    return {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks": ranks,
+            "devices": [d[1] for d in devs], "distinct_devices": len({d[1] for d in devs}), "device_name": devs[0][2]}
+
+
+# roofline kernel families of a step (ops.KernelTimer descriptors -> family name)
+def roofline_family(g, KT):
+    if g["KT"] != KT:
+        return None
+    if g["op"] == "wgrad":
+        return "weight_gradient" if g["Cin"] == 64 and g["Cout"] == 64 else None
+    if g["flip"] or g["var"] != "plain":
+        return None          # (the plain template instance: forward convs of the generator blocks)
+    if g["Cin"] == 64 and g["Cout"] == 64:
+        return "conv_fwd"
+    if g["Cin"] <= 4 and g["Cout"] == 64:
+        return "head_fwd"
+    if g["Cin"] == 64 and g["Cout"] <= 4:
+        return "tail_fwd"
+    return None
+
+
+CONV_KIND = {0: ("conv_mfma_kernel + conv_fixup_kernel (direct implicit GEMM, stream-K)", 1.0),
+             1: ("conv_wino_kernel + conv_wino_fixup_kernel (Winograd F(2,3) along W, stream-K)", 2.0 / 3.0),
+             2: ("conv_wino2d_kernel (Winograd F(2x2,3x3) over H and W, one software-pipelined workgroup per CU)", 4.0 / 9.0),
+             3: ("conv_narrow2_kernel (narrow output: taps in the GEMM N axis)", 1.0)}
+WGRAD_KIND = {0: ("conv_wgrad_kernel + conv_wgrad_reduce_kernel (direct, a workgroup per time tap)", 1.0),
+              1: ("conv_wgrad3_kernel + conv_wgrad3_reduce_kernel (direct, all taps per workgroup)", 1.0),
+              2: ("conv_wgradw_kernel + conv_wgradw_reduce_kernel (transposed Winograd F(2,3) along W)", 2.0 / 3.0),
+              3: ("conv_wgradw2_kernel + conv_wgradw2_reduce_kernel (transposed Winograd F(2x2,3x3) over H and W)", 4.0 / 9.0),
+              4: ("conv_wgrad_narrow2_kernel + conv_wgrad_narrow_reduce_kernel", 1.0)}
+
+
+def roofline_entries(by_shape, KT, lib):
+    """One roofline entry per kernel family from the live HIP-event timings {(family, B, Cin, Cout, T, H, W): (ms, launches, rank)}.
+    MFMA-bound families (64 -> 64 convs and their weight gradient): `achieved` = matrix-core flops the kernel EXECUTES per
+    launch / average launch time, `frac` = achieved / the fp32 MFMA peak (<= 1 by construction); the conv's algorithmic flops
+    (2 * Cin * Cout * taps per output voxel) are reported beside it as `algorithmic_tflops` with `work_ratio` =
+    executed / algorithmic (1 direct, 2/3 one-axis Winograd, 4/9 two-axis).  HBM-bound families (3 -> 64 heads, 64 -> 3 / 1
+    tails): `achieved` = algorithmic bytes / time in GB/s against the 8 TB/s HBM peak.  The returned object is the forward
+    conv family's entry (the step's dominant kernel) with every family under "families"."""
+    fams = {}
+    for k in by_shape:
+        fams.setdefault(k[0], []).append(k)
+    out = {}
+    taps = 9 * KT
+    for fam, keys in fams.items():
+        # finest level; among its launches the per-pass batch B = batch_size when some rank ran it (the shape the PMC traffic
+        # figures are measured on, and the shape an N = 1 run times: the merged generator pass runs the same kernel at B = 4,
+        # the batch-split schedules at B = 1)
+        key = max(keys, key=lambda k: (k[4] * k[5] * k[6], k[1] == 2, -k[1], k[3]))
+        ms, n, owner = by_shape[key]
+        _, B, Cin, Cout, T, H, W = key
+        shape5 = [B, Cin, T, H, W]
+        vox = float(B) * T * H * W
+        sec = ms * 1e-3
+        traffic, traffic_src = measured_traffic(fam, shape5)
+        if fam in ("conv_fwd", "weight_gradient"):
+            if fam == "conv_fwd":
+                kind = lib.hpvg_conv_fwd_kernel_kind(B, Cin, Cout, T, H, W, KT)
+                kname, ratio = CONV_KIND[kind]
+            else:
+                kind = lib.hpvg_conv_bwd_weight_kernel_kind(B, Cin, Cout, T, H, W, KT)
+                kname, ratio = WGRAD_KIND[kind]
+            flops = 2.0 * vox * Cin * Cout * taps
+            executed = flops * ratio
+            achieved = executed / sec / 1e12
+            ent = {"bound": "mfma", "kernel": "%s, 64->64 %s, fp32 v_mfma_f32_32x32x2_f32" % (kname, "3x3x3" if KT == 3 else "3x3"),
+                   "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                   "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                   "algorithmic_tflops": round(flops / sec / 1e12, 3), "work_ratio": round(ratio, 4),
+                   "flops_per_launch": flops, "executed_flops_per_launch": executed,
+                   "algorithmic_bytes": 4.0 * vox * (Cin + Cout) + 4.0 * Cin * Cout * taps,
+                   "hbm_frac_of_algorithmic_bytes": round((4.0 * vox * (Cin + Cout)) / sec / 1e9 / PEAK_HBM_GBS, 4)}
+        else:
+            kind = lib.hpvg_conv_fwd_kernel_kind(B, Cin, Cout, T, H, W, KT)
+            kname = CONV_KIND[kind][0] if fam == "tail_fwd" else "conv_mfma_kernel<4, ...> (3-channel input chunk) + conv_fixup_kernel"
+            nbytes = 4.0 * vox * (Cin + Cout) + 4.0 * Cin * Cout * taps
+            flops = 2.0 * vox * Cin * Cout * taps
+            achieved = nbytes / sec / 1e9
+            ent = {"bound": "hbm", "kernel": "%s, %d->%d %s" % (kname, Cin, Cout, "3x3x3" if KT == 3 else "3x3"),
+                   "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
+                   "algorithmic_bytes": nbytes, "flops_per_launch": flops, "flop_per_byte": round(flops / nbytes, 2),
+                   "mfma_frac": round(flops / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        ent.update({"family": fam, "traffic": traffic, "traffic_source": traffic_src, "shape": shape5, "cout": Cout,
+                    "avg_ms": round(ms, 4), "launches": n, "rank": owner})
+        out[fam] = ent
+    if not out:
+        return None
+    order = ["conv_fwd", "weight_gradient", "head_fwd", "tail_fwd"]
+    main = dict(out.get("conv_fwd") or out[sorted(out, key=order.index)[0]])
+    main["families"] = [out[f] for f in order if f in out]
+    return main
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,8 +361,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--stages", type=str, default="all", help="pyramid stages in a step, e.g. 0-9 or 9 (default: every stage of the config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stages", type=str, default="0-7",
-                    help="stages the CPU leg times (20 iterations at stages 0-3, 3 at 4-5, 1 at 6-7; 8-9 are extrapolated)")
+    ap.add_argument("--cpu-stages", type=str, default="all",
+                    help="stages the CPU leg times (default: every stage of the step; 1 warm-up + 20 timed iterations at stages "
+                         "0-3, 3 at 4-7, 1 at 8-9; nothing is extrapolated - a stage left out here is reported as not run)")
     ap.add_argument("--graph-stages", type=str, default="0-8",
                     help="stages whose iteration is captured once and replayed as a hipGraph (single-GPU path; the stage "
                          "holding the roofline kernel always stays eager so that its launches can be bracketed by events); "
@@ -304,6 +410,7 @@ def main():
 
     import hp_vae_gan_amd  # noqa: F401  (fails loudly if libhpvg.so is missing)
     from hp_vae_gan_amd import ops, lib as hplib
+    comm = comm_check(world, rank, device, backend, dev_index)
 
     if world > 1:
         from hp_vae_gan_amd import multigpu
@@ -350,9 +457,7 @@ def main():
     barrier()
     # ---- timed region: exactly K steps; the dominant kernel's launches are bracketed by HIP events on the launch stream
     KT = 1 if CONFIG == "image" else 3
-    # the plain template instance (what `rocprofv3 --stats` lists as conv_mfma_kernel<8, 3, 2, 4, 0>): forward convs of the
-    # generator blocks; the critic's activated convs run the bit-mask-writing variant and are not mixed into the figure
-    timer = ops.KernelTimer(match=lambda g: g["Cin"] == 64 and g["Cout"] == 64 and g["KT"] == KT and not g["flip"] and g["var"] == "plain")
+    timer = ops.KernelTimer(match=lambda g: roofline_family(g, KT))
     ops.set_kernel_timer(timer)
     stage_ev = {}
     import gc
@@ -379,7 +484,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the dominant kernel's launches, from every rank: on N > 1 the finest level's convs run on the rank(s) that own that
+    # the roofline kernels' launches, from every rank: on N > 1 the finest level's convs run on the rank(s) that own that
     # level (the last rank of a pipeline), not necessarily on rank 0
     by_shape = {k: v + (rank,) for k, v in timer.summary().items()}
     if world > 1:
@@ -394,59 +499,22 @@ def main():
     if rank == 0:
         nstage = len(stages)
         per_stage = {str(s): 1000.0 * args.steps / ev[0].elapsed_time(ev[1]) for s, ev in stage_ev.items()}
-        # dominant kernel: the 64->64 3x3x3 implicit-GEMM conv at the finest resident stage
-        roof = None
-        if by_shape:
-            # finest level; among its launches the per-pass batch B = batch_size when some rank ran it (the discriminator's
-            # convs on one GPU and in the pipelines: the shape the PMC traffic figure was measured on; the merged generator
-            # pass runs the same kernel at B = 4, the batch-split schedules at B = 1)
-            key = max(by_shape, key=lambda k: (k[2] * k[3] * k[4], k[0] == 2, -k[0]))
-            ms, n, owner = by_shape[key]
-            B, C, T, H, W = key
-            flops = 2.0 * B * 64 * 64 * (9 * KT) * T * H * W
-            achieved = flops / (ms * 1e-3) / 1e12
-            traffic, traffic_src = measured_traffic(key)
-            # which kernel ran these launches (conv_mfma.hip conv_use_wino: Winograd F(2,3) along W unless switched off or,
-            # for the 3x3 convs, below 24 K output positions): `achieved` / `frac` price the ALGORITHMIC flops of the conv
-            #  as the contract asks; the Winograd kernel EXECUTES 2/3 of them on the matrix cores, reported beside
-            mode = hplib.load().hpvg_conv_wino_config(-1, -1)
-            wmin = os.environ.get("HPVG_WINO_MIN")
-            wino = mode == 2 or (mode == 1 and B * T * H * W >= (int(wmin) if wmin else (0 if KT == 3 else 24000)))
-            wino2 = wino and hplib.load().hpvg_conv_wants_wino2d(B, 64, 64, T, H, W, KT) == 1
-            kname = ("conv_wino2d_kernel (64->64 %s fwd, Winograd F(2x2,3x3) over H and W, one software-pipelined workgroup per CU, fp32 v_mfma_f32_32x32x2_f32)"
-                     if wino2 else
-                     "conv_wino_kernel + conv_wino_fixup_kernel (64->64 %s fwd, Winograd F(2,3) along W, stream-K, fp32 v_mfma_f32_32x32x2_f32)"
-                     if wino else "conv_mfma_kernel + conv_fixup_kernel (64->64 %s fwd, stream-K, fp32 v_mfma_f32_32x32x2_f32)") % ("3x3x3" if KT == 3 else "3x3")
-            # matrix-core flops the kernel executes per algorithmic flop: 1 direct, 2/3 one-axis Winograd, 4/9 two-axis
-            executed = flops * (4.0 / 9.0 if wino2 else (2.0 / 3.0 if wino else 1.0))
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes": 4.0 * B * T * H * W * (64 + 64) + 4.0 * 64 * 64 * 9 * KT, "shape": list(key),
-                    "avg_ms": round(ms, 4), "launches": n, "flops_per_launch": flops, "rank": owner,
-                    "executed_flops_per_launch": executed, "matrix_pipe_frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        roof = roofline_entries(by_shape, KT, hplib.load())
         cpu = None
         if not args.no_cpu_baseline and world == 1 and CONFIG == "video":
-            cs = [s for s in parse(args.cpu_stages) if s in stages]
+            cs = stages if args.cpu_stages == "all" else [s for s in parse(args.cpu_stages) if s in stages]
             if cs:
                 threads = min(os.cpu_count() or 1, 16)
                 per = cpu_baseline(cs, threads)
                 tot = sum(per.values())
                 gpu_same = sum(1.0 / per_stage[str(s)] for s in cs)
-                # stages not run on the CPU: time = t(last measured stage) x iteration-GFLOP ratio
-                ref = max(cs)
-                est = {s: per[ref] * REF_ITER_GFLOP[s] / REF_ITER_GFLOP[ref] for s in stages if s not in per and s in REF_ITER_GFLOP}
-                full = None
-                if all(s in per or s in est for s in stages):
-                    full = round(len(stages) / (tot + sum(est.values())), 4)
                 cpu = {"value": round(len(cs) / tot, 4), "unit": "stage-iterations/s", "cores": threads, "kind": "port",
                        "sample": ("oracle train step (oracle/hpvg_oracle.py, torch CPU fp32, %d threads) at stages %s, same shapes as the GPU "
-                                  "run (B=2): 1 warm-up + %s timed iterations per stage; stages %s are NOT run: their time is "
-                                  "extrapolated as t(stage %d) x iteration-GFLOP ratio of SURVEY.md 8d" %
-                                  (threads, cs, {s: cpu_iters(s) for s in cs}, sorted(est), ref)),
-                       "per_stage_it_s": {str(s): round(1.0 / t, 4) for s, t in per.items()},
-                       "extrapolated_it_s": {str(s): round(1.0 / t, 5) for s, t in est.items()},
-                       "full_sweep_estimate": full,
+                                  "run (B=2): 1 warm-up + %s timed iterations per stage, every listed stage RUN (nothing extrapolated)" %
+                                  (threads, cs, {s: cpu_iters(s) for s in cs})),
+                       "per_stage_it_s": {str(s): round(1.0 / t, 5) for s, t in per.items()},
+                       "stages_not_run": [s for s in stages if s not in per],
+                       "seconds": round(sum(t * (cpu_iters(s) + 1) for s, t in per.items()), 1),
                        "gpu_value_same_sample": round(len(cs) / gpu_same, 3)}
         line = {
             "metric": "train iters/sec per pyramid scale, air_balloons 13f@144p",
@@ -461,7 +529,7 @@ def main():
                                             and parallelism_mode() != "levels" and CONFIG != "baseline"]),
                        "parallelism": _parallelism(world)},
             "per_stage_it_s": {k: round(v, 4) for k, v in sorted(per_stage.items(), key=lambda kv: int(kv[0]))},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "comm": comm,
         }
         print(json.dumps(line))
     if world > 1:

@@ -1669,6 +1669,17 @@ static int conv_fwd_impl(const float* x, const float* wp, const float* bias, con
   return KT == 3 ? dispatch_conv<4, 3>(a, p, S, s) : dispatch_conv<4, 1>(a, p, S, s);
 }
 
+// host only: which kernel family hpvg_conv_fwd_f32 / hpvg_conv_fwd_bits_f32 run this shape on (no prologue, no fp32 out-mask):
+// 0 = direct implicit GEMM (conv_mfma_kernel), 1 = Winograd F(2,3) along W (conv_wino_kernel: 2/3 of the direct matrix-core
+// work), 2 = Winograd F(2x2,3x3) (conv_wino2d_kernel: 4/9), 3 = the narrow-output kernel (Cout <= 4)
+int hpvg_conv_fwd_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  if (conv_is_narrow(Cin, Cout)) return 3;
+  if (!conv_use_wino(B, Cin, Cout, T, H, W, KT, false)) return 0;
+  if (conv_use_wino2d(wino2d_geom(B, Cin, Cout, T, H, W, KT), false)) return 2;
+  return plan_conv(B, Cin, Cout, T, H, W, KT, true, true).L != 0 ? 1 : 0;
+}
+
 // scratch the stream-K schedule of hpvg_conv_fwd_f32 wants for this shape
 size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return 0;

@@ -1663,6 +1663,17 @@ int hpvg_conv_bwd_weight_wino_config(int mode) {
   return g_wgradw_mode == 2 && four_byte_only ? 3 : (g_wgradw_mode == 2 && four_waves ? 4 : g_wgradw_mode);
 }
 
+// host only: which kernel family hpvg_conv_bwd_weight_f32 runs this shape on: 0 = conv_wgrad_kernel (direct, a workgroup per
+// time tap), 1 = conv_wgrad3_kernel (direct, all taps per workgroup), 2 = conv_wgradw_kernel (Winograd along W: 2/3 of the direct
+// matrix-core work), 4 = the narrow kernels (heads / tails)
+int hpvg_conv_bwd_weight_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
+  if (narrow_mode(Cin, Cout) >= 0) return 4;
+  if (wgradw_wanted(plan_wgradw(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT)) return 2;
+  if (KT == 3 && wgrad3_wanted(plan_wgrad3(B, Cin, Cout, T, H, W))) return 1;
+  return 0;
+}
+
 // host only: the tile plan of the Winograd weight-gradient kernel: out[0..9] as hpvg_conv_bwd_weight_plan
 int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
   if (!out || (KT != 1 && KT != 3) || B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;

@@ -39,6 +39,8 @@ _SIGS = {
     "hpvg_conv_mask_words": [I, I, I, I, I],
     "hpvg_conv_fwd_bits_f32": [P, P, P, P, I, P, P, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_fwd_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_fwd_kernel_kind": [I, I, I, I, I, I, I],
+    "hpvg_conv_bwd_weight_kernel_kind": [I, I, I, I, I, I, I],
     "hpvg_conv_narrow_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_wino_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_wino_config": [I, L],

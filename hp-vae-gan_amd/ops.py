@@ -23,11 +23,28 @@ class KernelTimer:
     duration measured live inside its timed region."""
 
     def __init__(self, match):
+        """match(desc) -> a family name (str) for launches to time, else None.  desc: {"op": "conv" | "wgrad", "Cin", "Cout",
+        "KT", and for convs "flip", "var"} in the kernel's view."""
         self.match = match
         self.events = []
 
+    def begin(self, desc):
+        fam = self.match(desc)
+        if not fam:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (fam, e0)
+
+    def end(self, tok, key):
+        if tok is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append(((tok[0],) + tuple(key), tok[1], e1))
+
     def summary(self):
-        """{(B, Cin, T, H, W): (average ms, launches)} - call after a device synchronise."""
+        """{(family, B, Cin, Cout, T, H, W): (average ms, launches)} - call after a device synchronise."""
         acc = {}
         for key, e0, e1 in self.events:
             ms = e0.elapsed_time(e1)
@@ -204,10 +221,9 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
     if in_affine is not None:
         sc, sh = in_affine
     timed = None
-    var = "pro" if in_affine is not None else ("mask" if (out_mask is not None or mask_bits is not None) else ("bits" if want_bits else "plain"))
-    if _kernel_timer is not None and _kernel_timer.match({"Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip, "var": var}):
-        timed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        timed[0].record()
+    if _kernel_timer is not None:
+        var = "pro" if in_affine is not None else ("mask" if (out_mask is not None or mask_bits is not None) else ("bits" if want_bits else "plain"))
+        timed = _kernel_timer.begin({"op": "conv", "Cin": cin_k, "Cout": cout_k, "KT": KT, "flip": flip, "var": var})
     nws = call("hpvg_conv_fwd_ws_bytes", B, cin_k, cout_k, T, H, W, KT)
     ws = workspace(nws, x.device) if nws else None
     if out_mask is not None and tuple(out_mask.shape) != tuple(shape):
@@ -225,8 +241,7 @@ def conv_fwd_raw(x, w, bias, out_lrelu=False, flip=False, in_affine=None, in_lre
              1 if out_lrelu else 0, ptr(_c(out_mask)) if out_mask is not None else None, ptr(ws),
              ctypes.c_size_t(ws.numel() if ws is not None else 0), B, cin_k, cout_k, T, H, W, KT, stream())
     if timed is not None:
-        timed[1].record()
-        _kernel_timer.events.append(((B, cin_k, T, H, W), timed[0], timed[1]))
+        _kernel_timer.end(timed, (B, cin_k, cout_k, T, H, W))
     return (y, bits) if want_bits else y
 
 
@@ -262,8 +277,11 @@ def conv_bwd_weight_raw(dy, x, w_shape, into=None):
     nbytes = call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT)
     ws = workspace(nbytes, dy.device)
     dw = into if into is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    timed = _kernel_timer.begin({"op": "wgrad", "Cin": Ci, "Cout": Co, "KT": KT, "bias": False}) if _kernel_timer is not None else None
     call("hpvg_conv_bwd_weight_f32", ptr(dy), ptr(x), None, None, 0, ptr(dw), 1 if into is not None else 0, ptr(ws),
          ctypes.c_size_t(ws.numel()), B, Ci, Co, T, H, W, KT, stream())
+    if timed is not None:
+        _kernel_timer.end(timed, (B, Ci, Co, T, H, W))
     return None if into is not None else dw
 
 
@@ -279,8 +297,11 @@ def conv_bwd_weight_bias_raw(dy, x, w_shape, into_w, into_b):
         return False
     nbytes = call("hpvg_conv_bwd_weight_ws_bytes", B, Ci, Co, T, H, W, KT)
     ws = workspace(nbytes, dy.device)
+    timed = _kernel_timer.begin({"op": "wgrad", "Cin": Ci, "Cout": Co, "KT": KT, "bias": True}) if _kernel_timer is not None else None
     call("hpvg_conv_bwd_weight_bias_f32", ptr(dy), ptr(x), ptr(into_w), 1, ptr(into_b), 1, ptr(ws), ctypes.c_size_t(ws.numel()),
          B, Ci, Co, T, H, W, KT, stream())
+    if timed is not None:
+        _kernel_timer.end(timed, (B, Ci, Co, T, H, W))
     return True
 
 

@@ -69,6 +69,10 @@ int hpvg_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, f
                            unsigned* bits_out, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT,
                            void* stream);
 int hpvg_conv_fwd_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only: tile plan */
+/* host only: the kernel family a plain launch of this shape runs on: 0 direct implicit GEMM, 1 Winograd F(2,3) along W (2/3 of
+ * the direct matrix-core work), 2 Winograd F(2x2,3x3) (4/9), 3 narrow-output kernel (Cout <= 4).  bench.py prices the
+ * roofline's executed flops with it. */
+int hpvg_conv_fwd_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT);
 /* Wide layers (kernel view Cin >= 8, Cout > 32) have a second kernel behind the same entry points: Winograd F(2,3) along W
  * (four products per output pair and (dt, dh) instead of six, summed over the channels before the output transform: 2/3 of
  * the matrix-core work; fp32, ~1e-6 of the output scale away from the direct kernel).  The weight pack carries both forms;
@@ -93,6 +97,9 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
                              float* dw, int accumulate, void* ws, size_t ws_bytes, int B, int Cin, int Cout, int T, int H,
                              int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
+/* host only: the kernel family of the weight gradient at this shape: 0 / 1 direct (a workgroup per time tap / all taps per
+ * workgroup), 2 Winograd along W (2/3 of the direct matrix-core work), 3 Winograd over H and W (4/9), 4 narrow kernels */
+int hpvg_conv_bwd_weight_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT);
 /* Wide layers (Cin > 4 and Cout > 4) have a Winograd weight-gradient kernel behind the same entry point (the transpose of
  * the forward F(2,3) along W: four products per pair of output columns and (dt, dh) instead of six, summed over all
  * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never, 1 = by size, 2 = every wide

@@ -489,9 +489,9 @@ def _spread(a, b):
     return None
 
 
-def wide_fixture(images, nets, losses, mutils, dims, scale_idx, ar=144.0 / 256.0):
+def wide_fixture(images, nets, losses, mutils, dims, scale_idx, ar=144.0 / 256.0, **okw):
     def opt():
-        return make_opt(nfc=64, latent_dim=128, vae_levels=3, min_size=32, max_size=256, img_size=256, ar=ar)
+        return make_opt(**dict(dict(nfc=64, latent_dim=128, vae_levels=3, min_size=32, max_size=256, img_size=256, ar=ar), **okw))
     one = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=1)
     with torch.backends.mkldnn.flags(enabled=False):   # 8 threads AND ATen's native conv kernels instead of oneDNN
         many = run_wide_step(images, nets, losses, mutils, opt(), dims, scale_idx, threads=8)
@@ -841,6 +841,13 @@ def main():
         # the 2-D path at the same widths (BASELINE configs[1]: train_image.py air_balloons.jpg, 248x186 -> ar 0.75)
         'wide2d_vae_s1.pt': lambda: wide_fixture(images, n2, losses, mutils, 2, 1, ar=186.0 / 248.0),
         'wide2d_gan_s4.pt': lambda: wide_fixture(images, n2, losses, mutils, 2, 4, ar=186.0 / 248.0),
+        # EVEN-width pyramids at the BASELINE channel widths: the kernels that own bench stages 8-9 (two-axis Winograd conv: even
+        # W; 16-byte eight-wave Winograd weight gradient: W % 4 == 0; `stage_tail`: H * W = 2 mod 4) inside whole steps.
+        # configs[3]'s geometry (--min-size 48: widths 48 / 61 / 78 / 99 ...): VAE stage 0 at 27 x 48, GAN stage 2 at 43 x 78
+        # (vae_levels 2 so that the 78-wide level is a GAN stage); a 128-wide pyramid whose GAN stage 2 is 40 x 72 (W % 4 == 0)
+        'wide3d_e48_vae_s0.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 0, min_size=48),
+        'wide3d_e78_gan_s2.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 2, min_size=48, vae_levels=2),
+        'wide3d_e72_gan_s2.pt': lambda: wide_fixture(images, n3, losses, mutils, 3, 2, min_size=48, max_size=128, img_size=128, vae_levels=2),
         # 8-level pyramids (BASELINE configs[3] / configs[4]: one level per GPU on 8 GPUs), tiny widths: the world-8 gloo tests
         'step3d_gan_s7.pt': lambda: run_stage_steps(images, n3, losses, mutils, make_opt(**small8), 3, 7, 1, seed=111),
         'baseline3d_sg_s7.pt': lambda: run_baseline_steps(images, n3, mutils, make_opt(Dsteps=1, Gsteps=1, alpha=10.0, train_depth=1, **small8),

@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # north_star tolerance: outputs within 1e-3 relative (fp32) of the reference's PyTorch-CPU path
 RTOL = 1e-3
+# reference-generated whole steps at the BASELINE channel widths (tests/golden/make_golden.py wide_fixture): the 256-wide
+# pyramid of configs[2] / configs[1], and EVEN-width pyramids (e48 / e78 / e72: W = 48, 78, 72) that put the two-axis Winograd
+# conv, the 16-byte Winograd weight gradient and the stage_tail instance inside a whole step
+WIDE_FIXTURES = ["wide3d_vae_s0.pt", "wide3d_gan_s3.pt", "wide2d_vae_s1.pt", "wide2d_gan_s4.pt",
+                 "wide3d_e48_vae_s0.pt", "wide3d_e78_gan_s2.pt", "wide3d_e72_gan_s2.pt"]
 
 
 def load_golden(name):

@@ -5,13 +5,75 @@ per-parameter gradient norms + strided samples, parameter UPDATES and buffers, a
 import pytest
 import torch
 
-from helpers import NoiseFeed, flat_to_named, hip_opt, load_golden, wide_compare, wide_inputs
+from helpers import WIDE_FIXTURES, NoiseFeed, flat_to_named, hip_opt, load_golden, wide_compare, wide_inputs
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fname", ["wide3d_vae_s0.pt", "wide3d_gan_s3.pt", "wide2d_vae_s1.pt", "wide2d_gan_s4.pt"])
+@pytest.mark.parametrize("fname", WIDE_FIXTURES)
 def test_wide_train_step_matches_reference(fname):
+    _run_wide_step(fname)
+
+
+# hpvg_conv_wino_config modes: 1 = by size (the default), 5 = the two-axis Winograd kernel wherever it can run (even W),
+# 3 / 4 = the one-axis kernel with the rows-as-in-memory / halo'd-band staging form, 0 = the direct kernel;
+# hpvg_conv_bwd_weight_wino_config modes: 1 = default, 2 = every wide layer, 4 = the 16-byte form on four waves, 3 = the 4-byte
+# form only, 0 = the direct weight-gradient kernels
+CONV_MODES = [1, 5, 3, 4, 0]
+WGRAD_MODES = [1, 2, 4, 3, 0]
+
+
+@pytest.mark.parametrize("fname", ["wide3d_e48_vae_s0.pt", "wide3d_e78_gan_s2.pt", "wide3d_e72_gan_s2.pt", "wide3d_gan_s3.pt"])
+def test_wide_train_step_under_every_forced_kernel(fname):
+    """The same reference-generated step with each conv kernel family x each weight-gradient family forced at run time: the
+    mask-bit hand-off (Conv.apply_bits), the fused bias gradient into the grad slots, the geometry-dependent weight packs and
+    the BatchNorm / spectral-norm wiring are the whole step's, the kernels are the ones that own bench stages 8-9
+    (W = 48 / 72: two-axis conv + 16-byte eight-wave weight gradient; W = 78: the stage_tail instance, H * W = 2 mod 4).
+    Same tolerances as the default-mode test: a failure here is a finding, not a tolerance question."""
+    from hp_vae_gan_amd import lib as hplib, ops
+    lib = hplib.load()
+    ran = []
+    try:
+        for cm in CONV_MODES:
+            for wm in WGRAD_MODES:
+                assert lib.hpvg_conv_wino_config(cm, -1) == cm
+                assert lib.hpvg_conv_bwd_weight_wino_config(wm) == wm
+                ops.weights_changed()
+                _run_wide_step(fname, "%s conv mode %d wgrad mode %d" % (fname, cm, wm))
+                ran.append((cm, wm))
+    finally:
+        lib.hpvg_conv_wino_config(1, -1)
+        lib.hpvg_conv_bwd_weight_wino_config(1)
+        ops.weights_changed()
+    assert len(ran) == len(CONV_MODES) * len(WGRAD_MODES)
+
+
+def test_forced_modes_select_the_kernels_they_name():
+    """what the forced modes of the test above mean at the fixtures' top-level shapes (host queries, no launches)"""
+    from hp_vae_gan_amd import lib as hplib
+    lib = hplib.load()
+    try:
+        for (T, H, W) in [(4, 27, 48), (4, 43, 78), (5, 40, 72)]:
+            for B in (2, 4):
+                geo = (B, 64, 64, T, H, W, 3)
+                lib.hpvg_conv_wino_config(5, -1)
+                assert lib.hpvg_conv_fwd_kernel_kind(*geo) == 2
+                for m in (3, 4):
+                    lib.hpvg_conv_wino_config(m, -1)
+                    assert lib.hpvg_conv_fwd_kernel_kind(*geo) == 1
+                lib.hpvg_conv_wino_config(0, -1)
+                assert lib.hpvg_conv_fwd_kernel_kind(*geo) == 0
+                for m in (1, 2, 3, 4):
+                    lib.hpvg_conv_bwd_weight_wino_config(m)
+                    assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) in (2, 3)
+                lib.hpvg_conv_bwd_weight_wino_config(0)
+                assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) in (0, 1)
+    finally:
+        lib.hpvg_conv_wino_config(1, -1)
+        lib.hpvg_conv_bwd_weight_wino_config(1)
+
+
+def _run_wide_step(fname, what=None):
     import hp_vae_gan_amd as hp  # noqa: F401
     from hp_vae_gan_amd import train as hp_train
     from hp_vae_gan_amd.modules import networks_2d, networks_3d
@@ -57,4 +119,4 @@ def test_wide_train_step_matches_reference(fname):
         for p in params:
             lr_by_id[id(p)] = lr
     lr_by_name = {n: lr_by_id.get(id(p)) for n, p in netG.named_parameters()}
-    wide_compare(fx, got, lambda n: lr_by_name[n], opt.lr_d, fname)
+    wide_compare(fx, got, lambda n: lr_by_name[n], opt.lr_d, what or fname)

@@ -3,7 +3,7 @@ against the reference-generated summaries of tests/golden/wide3d_*.pt (closed-fo
 import pytest
 import torch
 
-from helpers import load_golden, oracle_state, wide_compare, wide_inputs
+from helpers import WIDE_FIXTURES, load_golden, oracle_state, wide_compare, wide_inputs
 from oracle import hpvg_oracle as O
 
 
@@ -18,7 +18,7 @@ def _containers(opt, dims, s, gan):
     return netG.state_dict(), (netD.state_dict() if gan else None)
 
 
-@pytest.mark.parametrize("fname", ["wide3d_vae_s0.pt", "wide3d_gan_s3.pt", "wide2d_vae_s1.pt", "wide2d_gan_s4.pt"])
+@pytest.mark.parametrize("fname", WIDE_FIXTURES)
 def test_oracle_wide_step(fname):
     from helpers import opt_from
     fx = load_golden(fname)
