@@ -35,6 +35,7 @@ struct WgradArgs {
   int S0;  // KT == 3: persistent slots of the outer time taps (dt = 0, 2); the centre tap has S (>= S0)
   int in_lrelu;
   float* bpart;  // conv_wgradw_kernel only (else unused): [S][nob][64] per-slot sums of dY over the slot's tiles - the bias gradient
+  int order;     // conv_wgradw2_kernel only: the walk over the tiles (0 time-major, 1 plane-major)
 };
 
 
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 #include "conv_wgrad_wino.inl"
+#include "conv_wgrad_wino2.inl"
 
 // ------------------------------------------------------------------------------------------
 // Backward-weight of the 3x3x3 conv, second generation: ONE workgroup owns all 27 taps of a 64(o) x 32(c) block.
@@ -1250,6 +1252,78 @@ inline bool wgradw_wanted(const WPlan& p, int B, int Cin, int Cout, int T, int H
   return true;
 }
 
+// Tile plan of conv_wgradw2_kernel (Winograd over H and W): the 16-byte staging form with an EVEN tile height (rows of quads)
+// and its K loop's cost (16 MFMAs per two quads = 8 positions).  W must be a multiple of 4.
+WPlan plan_wgradw2_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  WPlan best{};
+  if (W % 4 != 0) return best;
+  double best_cost = 1e300;
+  const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
+  int prev_tw = 0;
+  // development: HPVG_WG2_FORCE="Th,Tw" restricts the search to that tile
+  static const int force = [] { const char* e = getenv("HPVG_WG2_FORCE"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
+  for (int ntw = W / 4; ntw >= 1; --ntw) {
+    const int Tw = 4 * hpvg_cdiv(hpvg_cdiv(W, ntw), 4);
+    if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;
+    prev_tw = Tw;
+    const int RSx = Tw + 8;
+    for (int Th = 2; Th <= H + 3; Th += 2) {
+      const int nth = hpvg_cdiv(H, Th);
+      const int thb = 2 * hpvg_cdiv(hpvg_cdiv(H, nth), 2);       // balanced, even
+      if (Th != thb && !(Tw % 8 != 0 && Th == 4 * hpvg_cdiv(thb, 4))) continue;   // (or the next multiple of 4: see QK below)
+      const int QK = Th * Tw;
+      const int DS = QK + 2, XS = (Th + 2) * RSx + 2;    // both 2 (mod 4); the X rows start at float 1
+      if (Th * (Tw / 4) > 128 || (Th + 2) * (Tw / 4 + 2) > 128) break;
+      const size_t lds = (size_t)2 * 64 * (DS + XS) * sizeof(float);
+      if (lds > 156 * 1024) break;
+      if (QK % 16 != 0) continue;                        // an even number of K steps (the kernel's loop body holds two)
+      const long ntiles = (long)B * T * nth * ntw;
+      const double work = (double)ntiles * (QK * 0.125 * 16.0 + 40.0);
+      if (force && force != Th * 1000 + Tw) continue;
+      if (work < best_cost) {
+        best_cost = work;
+        best = WPlan{Th, Tw, RSx, DS, XS, QK, nth, ntw, 0, nob, ncb, lds, 0, 2};
+      }
+    }
+  }
+  wgradw_slots(best, B, T, KT);
+  return best;
+}
+WPlan plan_wgradw2(int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  struct Key { int B, Cin, Cout, T, H, W, KT; };
+  struct Entry { Key k; WPlan p; };
+  constexpr int NE = 256;
+  static thread_local Entry cache[NE];
+  static thread_local int filled = 0;
+  for (int i = 0; i < filled; ++i) {
+    const Key& c = cache[i].k;
+    if (c.B == B && c.Cin == Cin && c.Cout == Cout && c.T == T && c.H == H && c.W == W && c.KT == KT) return cache[i].p;
+  }
+  const WPlan p = plan_wgradw2_search(B, Cin, Cout, T, H, W, KT);
+  if (filled < NE) cache[filled++] = Entry{Key{B, Cin, Cout, T, H, W, KT}, p};
+  return p;
+}
+inline size_t wgradw2_slab_bytes(const WPlan& p, int KT) { return (size_t)p.S * KT * p.nob * p.ncb * 16 * 4096 * sizeof(float); }
+inline size_t wgradw2_ws_bytes(const WPlan& p, int KT) { return 256 + wgradw2_slab_bytes(p, KT) + (size_t)p.S * p.nob * 64 * sizeof(float); }
+// Where the two-axis kernel is taken.  g_wgradw2: 0 = by size, 1 = never, 2 = wherever it can run (HPVG_WGRADW2 at start;
+// hpvg_conv_bwd_weight_wino_config modes 5 / 6 set 2 / 1).  By size: a workgroup must walk enough tiles to amortise its larger
+// slab (16 instead of 12 point tiles) and reduce: measured on MI355X (tools/perf_wgrad_wino.py), see DESIGN.md.
+int g_wgradw2 = -1;
+long g_wgradw2_min_tiles = 24;    // tiles per persistent workgroup from which the two-axis kernel is taken by default
+inline bool wgradw2_wanted(const WPlan& p2, int B, int Cin, int Cout, int T, int H, int W, int KT) {
+  if (g_wgradw2 < 0) {
+    const char* e = getenv("HPVG_WGRADW2");
+    g_wgradw2 = e ? atoi(e) : 0;
+    const char* m = getenv("HPVG_WGRADW2_MIN_TILES");
+    if (m) g_wgradw2_min_tiles = atol(m);
+  }
+  if (g_wgradw2 == 1 || p2.Th == 0 || Cin <= 4 || Cout <= 4) return false;
+  if (!wgradw_wanted(p2, B, Cin, Cout, T, H, W, KT)) return false;     // (the Winograd weight gradient switched off altogether)
+  if (g_wgradw2 == 2) return true;
+  const long ntiles = (long)B * T * p2.nth * p2.ntw;
+  return ntiles >= g_wgradw2_min_tiles * (long)p2.S;
+}
+
 // tile plan of conv_wgrad3_kernel: the same tile family as conv_wgrad_kernel under its own LDS budget (two dY tiles, four
 // 32-channel X planes, one row of zeros); S persistent workgroups per (64 output, 32 input channel) block pair
 struct W3Plan { int Th, Tw, RS, DS, XS, QK, nth, ntw, S, nob, ncb; size_t lds; long ntiles; bool ok; };
@@ -1365,6 +1439,8 @@ size_t hpvg_conv_bwd_weight_ws_bytes(int B, int Cin, int Cout, int T, int H, int
   }
   const WPlan pw = plan_wgradw(B, Cin, Cout, T, H, W, KT);
   if (g_wgradw_mode != 0 && pw.Th != 0 && wgradw_ws_bytes(pw, KT) > need) need = wgradw_ws_bytes(pw, KT);  // (any run-time mode)
+  const WPlan p2 = plan_wgradw2(B, Cin, Cout, T, H, W, KT);
+  if (g_wgradw_mode != 0 && p2.Th != 0 && wgradw2_ws_bytes(p2, KT) > need) need = wgradw2_ws_bytes(p2, KT);
   return need;
 }
 
@@ -1381,6 +1457,7 @@ int hpvg_conv_bwd_weight_f32(const float* dy, const float* x, const float* in_sc
 // does hpvg_conv_bwd_weight_bias_f32 produce the bias gradient for this layer (the Winograd weight-gradient kernel runs it)?
 int hpvg_conv_bwd_weight_fuses_bias(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3) || narrow_mode(Cin, Cout) >= 0) return 0;
+  if (wgradw2_wanted(plan_wgradw2(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT)) return 1;
   return wgradw_wanted(plan_wgradw(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT) ? 1 : 0;
 }
 // the weight gradient AND db[o] (+)= sum over batch and positions of dy - the conv's bias gradient - from the same launch:
@@ -1478,6 +1555,54 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
     return hpvg_launch_status();
   }
   if (in_scale) return HPVG_ERR_UNSUPPORTED;  // the fused-producer prologue needs the register-staged variant
+  {
+    const WPlan p2 = plan_wgradw2(B, Cin, Cout, T, H, W, KT);
+    if (wgradw2_wanted(p2, B, Cin, Cout, T, H, W, KT)) {
+      // ---- Winograd over H and W (conv_wgradw2_kernel): 16 point accumulators per time tap, transformed by the reduce kernel
+      if (ws_bytes < wgradw2_ws_bytes(p2, KT)) return HPVG_ERR_WORKSPACE;
+      WgradArgs a;
+      a.dy = dy; a.x = x; a.in_scale = nullptr; a.in_shift = nullptr;
+      a.part = (float*)((char*)ws + 256);
+      a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T; a.H = H; a.W = W;
+      a.Th = p2.Th; a.Tw = p2.Tw; a.RS = p2.RS; a.DS = p2.DS; a.XS = p2.XS; a.QK = p2.QK; a.nth = p2.nth; a.ntw = p2.ntw;
+      a.S = p2.S; a.S0 = p2.S0; a.ncb = p2.ncb; a.nob = p2.nob; a.in_lrelu = 0;
+      a.bpart = db ? (float*)((char*)ws + 256 + wgradw2_slab_bytes(p2, KT)) : nullptr;
+      static const int order_env = [] { const char* e = getenv("HPVG_WG2_ORDER"); return e ? atoi(e) : 0; }();
+      a.order = order_env;
+      hipStream_t s = (hipStream_t)stream;
+      const dim3 grid((KT == 3 ? 2 * p2.S0 + p2.S : p2.S) * p2.nob * p2.ncb);
+      const int gjd = hpvg_cdiv(p2.Th * (p2.Tw / 4), 64), gjx = hpvg_cdiv((p2.Th + 2) * (p2.Tw / 4 + 2), 64);
+#define HPVG_W2_LAUNCH(K, D, X)                                                                                        \
+  {                                                                                                                    \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw2_kernel<K, D, X>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
+        (void)hipGetLastError();                                                                                       \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X>), grid, dim3(256), p2.lds, s, a);                                 \
+  }
+#define HPVG_W2_PICK(K)                                                                                                \
+  if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1)                                                                    \
+  else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2)                                                                           \
+  else HPVG_W2_LAUNCH(K, 2, 2)
+      if (KT == 3) {
+        HPVG_W2_PICK(3)
+      } else {
+        HPVG_W2_PICK(1)
+      }
+#undef HPVG_W2_PICK
+#undef HPVG_W2_LAUNCH
+      int st2 = hpvg_launch_status();
+      if (st2 != HPVG_OK) return st2;
+      const int nbw2 = KT * p2.nob * p2.ncb * 64;
+      hipLaunchKernelGGL(conv_wgradw2_reduce_kernel, dim3(nbw2 + (db ? hpvg_cdiv(Cout, 64) : 0)), dim3(64, 16), 0, s,
+                         (const float*)a.part, dw, p2.S, p2.S0, KT, p2.nob, p2.ncb, Cout, Cin, accumulate, nbw2,
+                         (const float*)a.bpart, db, accumulate_db);
+      return hpvg_launch_status();
+    }
+  }
   {
     const WPlan pw = plan_wgradw(B, Cin, Cout, T, H, W, KT);
     if (wgradw_wanted(pw, B, Cin, Cout, T, H, W, KT)) {
@@ -1642,33 +1767,42 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
 
 // Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer, 3 = every
 // wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
-// HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; a negative mode only queries.
+// HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis
+// kernel (conv_wgradw2_kernel) wherever it can run (W % 4 == 0); 6 = the one-axis kernel only; a negative mode only queries.
 // Returns the mode in force.
 int hpvg_conv_bwd_weight_wino_config(int mode) {
   (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the defaults
+  (void)wgradw2_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);
   (void)plan_wgradw16_search(1, 8, 8, 1, 1, 1, 1);
-  static const int env_g16 = g_wgradw_g16, env_w8 = g_wgradw_w8;
+  static const int env_g16 = g_wgradw_g16, env_w8 = g_wgradw_w8, env_w2 = g_wgradw2;
   static int four_byte_only = 0, four_waves = 0;
   if (mode >= 0) {
     four_byte_only = mode == 3;
     four_waves = mode == 4;
     g_wgradw_w8 = four_waves ? 0 : env_w8;
     g_wgradw_mode = mode > 2 ? 2 : mode;
+    // 5: the two-axis kernel wherever it can run; 2 / 3 / 4 / 6: the one-axis kernel only (2: its default staging forms);
+    // 0 / 1: as the process started (HPVG_WGRADW2)
+    g_wgradw2 = mode == 5 ? 2 : (mode == 2 || mode == 3 || mode == 4 || mode == 6 ? 1 : env_w2);
     const int g16 = mode == 3 ? 0 : env_g16;
     if (g16 != g_wgradw_g16) {
       g_wgradw_g16 = g16;
       ++g_wgradw_gen;
     }
   }
-  return g_wgradw_mode == 2 && four_byte_only ? 3 : (g_wgradw_mode == 2 && four_waves ? 4 : g_wgradw_mode);
+  if (g_wgradw_mode == 2 && g_wgradw2 == 2) return 5;
+  if (g_wgradw_mode == 2 && four_byte_only) return 3;
+  if (g_wgradw_mode == 2 && four_waves) return 4;
+  return g_wgradw_mode;
 }
 
 // host only: which kernel family hpvg_conv_bwd_weight_f32 runs this shape on: 0 = conv_wgrad_kernel (direct, a workgroup per
 // time tap), 1 = conv_wgrad3_kernel (direct, all taps per workgroup), 2 = conv_wgradw_kernel (Winograd along W: 2/3 of the direct
-// matrix-core work), 4 = the narrow kernels (heads / tails)
+// matrix-core work), 3 = conv_wgradw2_kernel (Winograd over H and W: 4/9), 4 = the narrow kernels (heads / tails)
 int hpvg_conv_bwd_weight_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1 || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
   if (narrow_mode(Cin, Cout) >= 0) return 4;
+  if (wgradw2_wanted(plan_wgradw2(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT)) return 3;
   if (wgradw_wanted(plan_wgradw(B, Cin, Cout, T, H, W, KT), B, Cin, Cout, T, H, W, KT)) return 2;
   if (KT == 3 && wgrad3_wanted(plan_wgrad3(B, Cin, Cout, T, H, W))) return 1;
   return 0;

@@ -1,0 +1,417 @@
+// Weight gradient of the wide 3x3 / 3x3x3 convs with the TRANSPOSE of the forward Winograd F(2x2, 3x3) (conv_wino2d.inl) -
+// included by conv_wgrad.hip inside its anonymous namespace (shares WgradArgs, the zero word and the 16-byte staging form
+// with conv_wgradw_kernel, whose structure it keeps: one time tap and one 64 x 64 (o, c) block per persistent workgroup, one
+// 32 x 32 sub-block per wave, two LDS tile buffers filled by LDS-DMA in the shadow of the MFMAs, one partial slab at the end).
+//
+// Same reference call sites as conv_wgrad_kernel (the weight half of aten::convolution_backward, train_video.py:182,200,
+// train_image.py:193,215, and the gradient penalty's double backward, modules/utils.py:14-18).
+//
+// For a 2 x 2 block of output positions ("quad": rows 2R, 2R+1, columns 2C, 2C+1) with gradients y (2 x 2) and the 4 x 4 input
+// patch d (rows 2R-1..2R+2, columns 2C-1..2C+2) of one time tap, the 36 multiplies of the nine in-plane taps
+//       g[a][b] += sum_{r,s} y[r][s] d[r+a][s+b]
+// are regrouped into 16:  M = (A y A^T) (.) (B^T d B),  g += G^T M G,  with the F(2,3) matrices of conv_wgrad_wino.inl along
+// both axes (A = [[1,0],[1,1],[1,-1],[0,-1]], B^T d = (d0-d2, d1+d2, d2-d1, d1-d3), G^T m = (m0+(m1+m2)/2, (m1-m2)/2,
+// (m1+m2)/2+m3)).  Every point of M is summed over ALL quads, planes and samples first - the K axis of the GEMM counts quads -
+// and the (linear) output transform G^T . G runs once per weight in the reduce kernel.  GEMM per (dt, point): M = o, N = c,
+// K = quads, two per v_mfma_f32_32x32x2_f32: 16 MFMAs per pair of quads instead of 36 (direct) or 24 (one-axis): 4/9 of the
+// direct matrix-core work.  fp32 throughout.  The kernel works with A' = |A| (last row + instead of -: no negations in the K
+// loop); the reduce kernel gives point (i, j) the sign s_i s_j, s = (1, 1, 1, -1).
+//
+// Sixteen points x 16 registers = 256 accumulator registers per wave: one wave per SIMD (256 AGPRs + 256 VGPRs), and the K step
+// is laid out in 16 slots of one MFMA + a unit of other work that fits its 64-cycle shadow, pinned with sched_barrier (the
+// scheme of conv_wino2d_kernel): slot 0 the LDS reads of the next step's operands, 3 the vertical pass of its dY quad, 4-7 the
+// vertical pass of its input patch, 8-11 the horizontal pass, 12-15 the horizontal pass of the dY quad, 1 / 5 / 9 (/ 13) an
+// LDS-DMA piece of the next tile.
+// Tiles: Th x Tw output positions, Th even, Tw and the band origins multiples of 4 (W a multiple of 4): the 16-byte staging form
+// of conv_wgradw_kernel - a dY row is Tw floats, an X row Tw + 8 floats from column w0 - 4 one float into its channel row, so
+// that the patch pairs (first column w0 + 2C - 1) are 8-byte aligned; groups outside the image are zero-sourced, rows past H
+// too (odd H: the second row of the last quad row holds zeros on both sides).
+
+// a.order: the walk over the tiles.  0: time-major (tile = ((b * nth + th) * ntw + tw) * T + t: the slots of an XCD hold one
+// spatial tile at neighbouring t); 1: plane-major (tile = ((b * T + t) * nth + th) * ntw + tw: the slots of an XCD hold
+// neighbouring tiles of one plane, which share halo columns / rows and the other halves of their 128-byte lines in that XCD's L2)
+template <int KT, int NJD, int NJX>
+__global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NW = 4, NT = 256, NCH = 16, LW = 64, PW = 256;
+  constexpr int NP = NJD + NJX;
+  constexpr int PS = NP == 4 ? 4 : 3;         // LDS-DMA piece slots per K step (slots 1, 5, 9 (, 13))
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int oblk = wave >> 1, cblk = wave & 1;
+  const int nz = a.nob * a.ncb;
+  const int L = hpvg_xcd_remap(blockIdx.x, gridDim.x);
+  const int Stot = KT == 3 ? 2 * a.S0 + a.S : a.S;
+  const int idx = L % Stot;
+  const int z = L / Stot;
+  int dt = 0, slot = idx, nslot = a.S;
+  if (KT == 3) {
+    if (idx < 3 * a.S0) {
+      dt = idx % 3;
+      slot = idx / 3;
+      nslot = dt == 1 ? a.S : a.S0;
+    } else {
+      dt = 1;
+      slot = a.S0 + idx - 3 * a.S0;
+    }
+  }
+  const int ob = z / a.ncb, cb = z % a.ncb;
+  const int RS = a.RS, DS = a.DS, XS = a.XS, Tw = a.Tw;
+  const int BUF = 64 * (DS + XS);
+  const long HW = (long)a.H * a.W;
+  const long cstride = (long)a.T * HW;
+  const bool active = (ob * 64 + oblk * 32 < a.Cout) && (cb * 64 + cblk * 32 < a.Cin);
+  int no = a.Cout - ob * 64; if (no > 64) no = 64;
+  int nc = a.Cin - cb * 64;  if (nc > 64) nc = 64;
+  const int pt = (KT == 3 ? 1 : 0);
+  const int ntiles = a.B * a.T * a.nth * a.ntw;
+
+  f32x16 acc[16];   // [i][j]: point (i = vertical, j = horizontal)
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+  // bias gradient on the side (see conv_wgradw_kernel): the centre-tap workgroups' first input-channel half holds the sum of
+  // every dY quad of its 32 output channels (the point (1, 1) of A' y A'^T)
+  const float bflag = (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) ? 1.f : 0.f;
+  float bsum = 0.f, brun = 0.f, bcomp = 0.f;
+
+  for (int i = tid; i < 2 * BUF; i += NT) lds[i] = 0.f;
+
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* dptr[NJD];
+  const char* xptr[NJX];
+  unsigned dstr[NJD], xstr[NJX];
+  bool dln[NJD], xln[NJX];
+  const int gpr = Tw >> 2, gprx = gpr + 2;          // 16-byte groups per dY / X row
+#pragma unroll
+  for (int j = 0; j < NJD; ++j) dln[j] = j * LW + lane < a.Th * gpr;
+#pragma unroll
+  for (int j = 0; j < NJX; ++j) xln[j] = j * LW + lane < (a.Th + 2) * gprx;
+  const unsigned cbytes = (unsigned)(cstride * 4) * (unsigned)NW;   // to the next channel this wave stages
+  auto decode = [&](int tile, int& b, int& t, int& th_i, int& tw_i) __attribute__((always_inline)) {
+    if (a.order == 0) {
+      t = tile % a.T;
+      int r = tile / a.T;
+      tw_i = r % a.ntw;
+      r /= a.ntw;
+      th_i = r % a.nth;
+      b = r / a.nth;
+    } else {
+      tw_i = tile % a.ntw;
+      int r = tile / a.ntw;
+      th_i = r % a.nth;
+      r /= a.nth;
+      t = r % a.T;
+      b = r / a.T;
+    }
+  };
+  auto setup = [&](int tile) {
+    int b, t, th_i, tw_i;
+    decode(tile, b, t, th_i, tw_i);
+    const int tt = t + dt - pt;
+    const bool tok = tt >= 0 && tt < a.T;
+    const int h0 = th_i * a.Th, w0 = tw_i * Tw;
+    const float* dyb = a.dy + (((long)b * a.Cout + ob * 64 + wave) * a.T + t) * HW;
+    const float* xb = a.x + (((long)b * a.Cin + cb * 64 + wave) * a.T + (tok ? tt : 0)) * HW;
+#pragma unroll
+    for (int j = 0; j < NJD; ++j) {
+      const int p = j * LW + lane;
+      const int hh = p / gpr, ww = 4 * (p - hh * gpr);
+      const int gh = h0 + hh, gw = w0 + ww;
+      const bool ok = hh < a.Th && gh < a.H && gw < a.W;
+      dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
+      dstr[j] = ok ? cbytes : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NJX; ++j) {
+      const int p = j * LW + lane;
+      const int hh = p / gprx, ww = 4 * (p - hh * gprx) - 3;
+      const int gh = h0 + hh - 1, gw = w0 + ww - 1;
+      const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
+      xstr[j] = ok ? cbytes : 0u;
+    }
+  };
+  auto tile_has_work = [&](int tile) __attribute__((always_inline)) -> bool {
+    int b, t, th_i, tw_i;
+    decode(tile, b, t, th_i, tw_i);
+    const int tt = t + dt - pt;
+    return tt >= 0 && tt < a.T;
+  };
+  float* dma_d = lds;
+  float* dma_x = lds;
+  auto dma_begin = [&](float* buf) {
+    dma_d = buf + wave * DS;
+    dma_x = buf + 64 * DS + wave * XS + 1;
+  };
+#define WG2_PIECE(SRC, DST) __builtin_amdgcn_global_load_lds((gptr_t)(SRC), (lptr_t)(DST), 16, 0, 0);
+  int cnext = NCH;                 // next channel row (of this wave's 16) to stage; NCH = nothing left
+  // piece q (dY pieces first) of the channel row this wave stages next; the last piece of a row moves on
+  auto dma_piece = [&](int q) __attribute__((always_inline)) {
+    if (cnext < NCH) {
+      const int ch = NW * cnext + wave;
+#pragma unroll
+      for (int j = 0; j < NJD; ++j)
+        if (q == j) {
+          if (ch < no && dln[j]) WG2_PIECE(dptr[j], dma_d + j * PW);
+          dptr[j] += dstr[j];
+        }
+#pragma unroll
+      for (int j = 0; j < NJX; ++j)
+        if (q == NJD + j) {
+          if (ch < nc && xln[j]) WG2_PIECE(xptr[j], dma_x + j * PW);
+          xptr[j] += xstr[j];
+        }
+      if (q == NP - 1) {
+        dma_d += NW * DS;
+        dma_x += NW * XS;
+        ++cnext;
+      }
+    }
+  };
+  auto dma_channel = [&]() {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) dma_piece(q);
+  };
+
+  int tile = slot;
+  __syncthreads();  // zero fill done
+  if (tile < ntiles) {
+    setup(tile);
+    dma_begin(lds);
+    cnext = 0;
+    while (cnext < NCH) dma_channel();
+  }
+  __syncthreads();  // (waits for the DMA: pending LDS-DMA counts on vmcnt)
+
+  const int nsteps = a.QK >> 3;  // K-loop iterations: two quads = 8 positions = ONE MFMA k-step per point
+  int cur = 0;
+  for (; tile < ntiles; tile += nslot) {
+    const int next = tile + nslot;
+    const bool have_next = next < ntiles;
+    float* bufc = lds + cur * BUF;
+    cnext = NCH;
+    if (have_next) {
+      setup(next);
+      dma_begin(lds + (cur ^ 1) * BUF);
+      cnext = 0;
+    }
+#ifdef HPVG_ABLW2_NOMMA
+    if (false) {   // development ablation (timing only): everything but the K loop
+#else
+    if (active && tile_has_work(tile)) {
+#endif
+      // this lane's quad of step st: quad 2 st + half of the tile's row-major quad index (Tw / 2 quads per quad row, an even
+      // count: both halves of a step sit in the same quad row)
+      const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
+      const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half + 4;
+      int dyo = 0, xo = 0, wc = 0, ls = 0;   // offsets of the step being LOADED (steps are loaded in order, then wrap)
+      wf32x2a ry[2], rx[4][2];           // raw operands of the next step
+      float tn[4][4], rv[4][2];
+      float yA[16], vA[16], yB[16], vB[16];
+#define WG2_LOAD()                                                                          \
+  {                                                                                         \
+    ry[0] = *reinterpret_cast<const wf32x2a*>(dl + dyo);                                    \
+    ry[1] = *reinterpret_cast<const wf32x2a*>(dl + dyo + Tw);                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                      \
+      rx[r_][0] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RS);                     \
+      rx[r_][1] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RS + 2);                 \
+    }                                                                                       \
+    dyo += 4;                                                                               \
+    xo += 4;                                                                                \
+    if (++wc == gpr) { wc = 0; dyo += Tw; xo += 2 * RS - Tw; }                              \
+    if (++ls == nsteps) { ls = 0; wc = 0; dyo = 0; xo = 0; }                                \
+  }
+// vertical pass of the dY quad: rv[i][s] = (A' y)[i][s]
+#define WG2_YV()                                                                            \
+  {                                                                                         \
+    rv[0][0] = ry[0][0]; rv[0][1] = ry[0][1];                                               \
+    rv[1][0] = ry[0][0] + ry[1][0]; rv[1][1] = ry[0][1] + ry[1][1];                         \
+    rv[2][0] = ry[0][0] - ry[1][0]; rv[2][1] = ry[0][1] - ry[1][1];                         \
+    rv[3][0] = ry[1][0]; rv[3][1] = ry[1][1];                                               \
+  }
+// horizontal pass of row I: Y[I][*]
+#define WG2_YH(I, Y)                                                                        \
+  {                                                                                         \
+    Y[(I) * 4 + 0] = rv[I][0];                                                              \
+    Y[(I) * 4 + 1] = rv[I][0] + rv[I][1];                                                   \
+    Y[(I) * 4 + 2] = rv[I][0] - rv[I][1];                                                   \
+    Y[(I) * 4 + 3] = rv[I][1];                                                              \
+  }
+// vertical pass of patch column C: tn[i][C] = (B^T d)[i][C]
+#define WG2_XV(C)                                                                           \
+  {                                                                                         \
+    const float d0_ = rx[0][(C) >> 1][(C) & 1], d1_ = rx[1][(C) >> 1][(C) & 1];             \
+    const float d2_ = rx[2][(C) >> 1][(C) & 1], d3_ = rx[3][(C) >> 1][(C) & 1];             \
+    tn[0][C] = d0_ - d2_; tn[1][C] = d1_ + d2_; tn[2][C] = d2_ - d1_; tn[3][C] = d1_ - d3_; \
+  }
+// horizontal pass of row I: V[I][*]
+#define WG2_XH(I, V)                                                                        \
+  {                                                                                         \
+    V[(I) * 4 + 0] = tn[I][0] - tn[I][2];                                                   \
+    V[(I) * 4 + 1] = tn[I][1] + tn[I][2];                                                   \
+    V[(I) * 4 + 2] = tn[I][2] - tn[I][1];                                                   \
+    V[(I) * 4 + 3] = tn[I][1] - tn[I][3];                                                   \
+  }
+#define WG2_TRANSFORM(Y, V)                                                                 \
+  {                                                                                         \
+    WG2_YV() WG2_XV(0) WG2_XV(1) WG2_XV(2) WG2_XV(3)                                        \
+    WG2_XH(0, V) WG2_XH(1, V) WG2_XH(2, V) WG2_XH(3, V)                                     \
+    WG2_YH(0, Y) WG2_YH(1, Y) WG2_YH(2, Y) WG2_YH(3, Y)                                     \
+  }
+#ifdef HPVG_ABLW2_NODMA
+#define WG2_DMA(Q) { if (cnext < NCH && (Q) == NP - 1) ++cnext; }
+#else
+#define WG2_DMA(Q) dma_piece(Q);
+#endif
+// slot K of a step of parity SP: one MFMA on the current operands (YC, VC) + a unit of the next step's preparation (into YN, VN)
+#define WG2_SLOT(SP, K, YC, VC, YN, VN, MORE)                                                                      \
+  {                                                                                                                \
+    acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(YC[K], VC[K], acc[K], 0, 0, 0);                                  \
+    if ((K) == 0) bsum = __builtin_fmaf(bflag, YC[5], bsum);                                                       \
+    if (MORE) {                                                                                                    \
+      if ((K) == 0) WG2_LOAD()                                                                                     \
+      if ((K) == 3) WG2_YV()                                                                                       \
+      if ((K) >= 4 && (K) < 8) WG2_XV((K) & 3)                                                                     \
+      if ((K) >= 8 && (K) < 12) WG2_XH((K) & 3, VN)                                                                \
+      if ((K) >= 12) WG2_YH((K) & 3, YN)                                                                           \
+    }                                                                                                              \
+    if (((K) & 3) == 1 && ((K) >> 2) < PS) WG2_DMA(((SP) * PS + ((K) >> 2)) % NP)                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  }
+#define WG2_STEP(SP, YC, VC, YN, VN, MORE)                                                                         \
+  {                                                                                                                \
+    WG2_SLOT(SP, 0, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 1, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 2, YC, VC, YN, VN, MORE)    \
+    WG2_SLOT(SP, 3, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 4, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 5, YC, VC, YN, VN, MORE)    \
+    WG2_SLOT(SP, 6, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 7, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 8, YC, VC, YN, VN, MORE)    \
+    WG2_SLOT(SP, 9, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 10, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 11, YC, VC, YN, VN, MORE)  \
+    WG2_SLOT(SP, 12, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 13, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 14, YC, VC, YN, VN, MORE) \
+    WG2_SLOT(SP, 15, YC, VC, YN, VN, MORE)                                                                         \
+  }
+      // first step's operands (nothing to hide them behind), then two steps per iteration: A -> B -> A.  ONE loop body holds
+      // every MFMA of the kernel (nsteps is even: the planner's tiles have Th * Tw % 16 == 0): hipcc gives the accumulators of a
+      // peeled step other registers and copies / spills all 256 around it.  The last step therefore prepares operands as well
+      // (WG2_LOAD wraps to the tile's first step: in-bounds reads whose results are dropped).
+      WG2_LOAD()
+      WG2_TRANSFORM(yA, vA)
+      for (int st = 0; st < nsteps; st += 2) {
+        WG2_STEP(0, yA, vA, yB, vB, true)
+        WG2_STEP(1, yB, vB, yA, vA, true)
+      }
+#undef WG2_STEP
+#undef WG2_SLOT
+#undef WG2_DMA
+#undef WG2_TRANSFORM
+#undef WG2_XH
+#undef WG2_XV
+#undef WG2_YH
+#undef WG2_YV
+#undef WG2_LOAD
+    }
+    {   // this tile's bias sum into the running one (Kahan)
+      const float yk = bsum - bcomp, tk = brun + yk;
+      bcomp = (tk - brun) - yk;
+      brun = tk;
+      bsum = 0.f;
+    }
+    while (cnext < NCH) dma_channel();  // whatever did not fit into the K loop (short loops, idle waves, skipped tiles)
+    __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
+    cur ^= 1;
+  }
+#undef WG2_PIECE
+
+  if (a.bpart != nullptr && dt == pt && cb == 0 && cblk == 0) {
+    // the two half-waves hold the even / odd quads of the same channels
+    const float tot = brun + __shfl_xor(brun, 32, 64);
+    if (half == 0) a.bpart[((long)slot * a.nob + ob) * 64 + oblk * 32 + l31] = active ? tot : 0.f;
+  }
+  // ---- partial slab: part[s][dt][z][i*4 + j][o64][c64]
+  float* pp = a.part + ((((long)slot * KT + dt) * nz + z) * 16) * 4096;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = oblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      pp[(long)k * 4096 + row * 64 + cblk * 32 + l31] = active ? acc[k][e] : 0.f;
+    }
+}
+
+// dW[o][c][dt][a][b] = (G^T M G)[a][b],  M[i][j] = s_i s_j sum_s part[s][dt][z][i*4 + j][o%64][c%64].  A block is one (dt, z, o)
+// row of 64 input channels x 16 threadIdx.y = (slot group g of 4, point row i): each thread sums the slots [g*S/4, (g+1)*S/4)
+// of its four points (i, 0..3) in order (four independent chains), the group sums are added in group order through LDS
+// (reproducible), then nine of the sixteen y rows apply the output transform for one (a, b) each.  Blocks past nbw: the bias
+// gradient (as in conv_wgradw_reduce_kernel).
+__global__ __launch_bounds__(1024) void conv_wgradw2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S1,
+                                                                   int S0, int KT, int nob, int ncb, int Cout, int Cin,
+                                                                   int accumulate, int nbw, const float* __restrict__ bpart,
+                                                                   float* __restrict__ db, int accumulate_db) {
+  __shared__ float sm[4][16][64];
+  const int y = threadIdx.y, tx = threadIdx.x;
+  if ((int)blockIdx.x >= nbw) {
+    double* smd = reinterpret_cast<double*>(&sm[0][0][0]);     // [16][64] doubles
+    const int o = ((int)blockIdx.x - nbw) * 64 + tx;
+    double t0 = 0.0;
+    if (o < Cout) {
+      const float* q = bpart + (long)(o / 64) * 64 + (o & 63);
+      const long sstride = (long)nob * 64;
+      const int hi = (int)((long)(y + 1) * S1 / 16);
+      for (int sl = (int)((long)y * S1 / 16); sl < hi; ++sl) t0 += (double)q[(long)sl * sstride];
+    }
+    smd[y * 64 + tx] = t0;
+    __syncthreads();
+    if (y == 0 && o < Cout) {
+      double t = smd[tx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t += smd[k * 64 + tx];
+      db[o] = accumulate_db ? db[o] + (float)t : (float)t;
+    }
+    return;
+  }
+  int r = blockIdx.x;
+  const int o64 = r % 64; r /= 64;
+  const int z = r % (nob * ncb); r /= (nob * ncb);
+  const int dt = r;
+  const int o = (z / ncb) * 64 + o64, c = (z % ncb) * 64 + tx;
+  const bool live = o < Cout && c < Cin;
+  const int S = (KT == 3 && dt != 1) ? S0 : S1;  // slots that wrote a slab for this time tap
+  const long per_s = (long)KT * nob * ncb * 16 * 4096;
+  const int g = y >> 2, i = y & 3;
+  const float* p0 = part + (((long)dt * nob * ncb + z) * 16 + i * 4) * 4096 + o64 * 64 + tx;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  if (live) {
+    const int hi = (int)((long)(g + 1) * S / 4);
+    for (int sl = (int)((long)g * S / 4); sl < hi; ++sl) {
+      const float* q = p0 + (long)sl * per_s;
+      m0 += q[0];
+      m1 += q[4096];
+      m2 += q[2 * 4096];
+      m3 += q[3 * 4096];
+    }
+  }
+  sm[g][i * 4 + 0][tx] = m0;
+  sm[g][i * 4 + 1][tx] = m1;
+  sm[g][i * 4 + 2][tx] = m2;
+  sm[g][i * 4 + 3][tx] = m3;
+  __syncthreads();
+  if (y < 9 && live) {
+    const int ta = y / 3, tb = y - 3 * ta;
+    // G^T along one axis: tap 0 = m0 + (m1 + m2)/2, tap 1 = (m1 - m2)/2, tap 2 = (m1 + m2)/2 + m3, with m3 carrying the sign -1
+    float col[4];   // col[i] = (row i of M) transformed along j for tap tb
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      float m[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = ((sm[0][ii * 4 + j][tx] + sm[1][ii * 4 + j][tx]) + sm[2][ii * 4 + j][tx]) + sm[3][ii * 4 + j][tx];
+      const float hs = 0.5f * (m[1] + m[2]), hd = 0.5f * (m[1] - m[2]);
+      col[ii] = tb == 0 ? m[0] + hs : (tb == 1 ? hd : hs - m[3]);
+    }
+    const float hs = 0.5f * (col[1] + col[2]), hd = 0.5f * (col[1] - col[2]);
+    const float gv = ta == 0 ? col[0] + hs : (ta == 1 ? hd : hs - col[3]);
+    float* dst = dw + ((((long)o * Cin + c) * KT + dt) * 3 + ta) * 3 + tb;
+    *dst = accumulate ? *dst + gv : gv;
+  }
+}

@@ -231,6 +231,9 @@ def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, win
     # form on four waves (mode 2: eight)
     (1, 64, 64, (3, 7, 8)), (2, 64, 64, (2, 9, 36)), (1, 70, 130, (2, 5, 52)), (1, 64, 64, (2, 20, 204)), (2, 64, 64, (31, 256)),
     (1, 24, 40, (3, 3, 4)), (1, 64, 64, (1, 50, 100)),
+    # (mode 5: the two-axis kernel on every W % 4 == 0 shape above - odd H, H = 1, tiles padded to an even number of K steps,
+    # several pieces per row, ragged bands and channel blocks - and on these: one tile exactly, a single row, 2-D one quad row)
+    (1, 64, 64, (2, 6, 16)), (2, 64, 64, (3, 1, 4)), (1, 64, 64, (2, 12)), (2, 70, 40, (2, 13, 24)),
 ])
 def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(ops, B, Cin, Cout, sp):
     """conv_wgradw_kernel (transposed F(2,3) along W, output transform in its reduce kernel; forced for every wide layer)
@@ -250,8 +253,11 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     try:
         want_db = gy.sum(dim=[0] + list(range(2, 2 + nd)))
         bbase = _rand(Cout, seed=35).to(DEV)
-        for mode in (2, 3, 4, 0):
+        for mode in (2, 3, 4, 5, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
+            if Cin > 4 and Cout > 4:   # mode 5 = the two-axis kernel wherever W is a multiple of 4, the one-axis kernel elsewhere
+                kind = lib.hpvg_conv_bwd_weight_kernel_kind(B, Cin, Cout, sp[0] if nd == 3 else 1, sp[-2], sp[-1], 3 if nd == 3 else 1)
+                assert kind == ((3 if sp[-1] % 4 == 0 else 2) if mode == 5 else (2 if mode >= 2 else kind)) and (mode or kind in (0, 1))
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
             assert ops.conv_bwd_weight_raw(gyd, xd, w.shape, into=acc) is None
@@ -267,12 +273,13 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
     finally:
         lib.hpvg_conv_bwd_weight_wino_config(prev)
     for mode, (dw, acc) in res.items():
-        tag = {2: "wino.", 3: "wino4.", 4: "wino16x4waves.", 0: "direct."}[mode]
+        tag = {2: "wino.", 3: "wino4.", 4: "wino16x4waves.", 5: "wino2axis.", 0: "direct."}[mode]
         assert_close(dw, want, RTOL, tag + "dw")
         assert_close(acc - base, want, RTOL, tag + "dw.accumulate", atol=1e-5 * float(base.abs().max()))
     assert_close(res[2][0], res[0][0], 3e-5, "wino-vs-direct.dw")
     assert_close(res[3][0], res[0][0], 3e-5, "wino4-vs-direct.dw")
     assert_close(res[4][0], res[0][0], 3e-5, "wino16x4waves-vs-direct.dw")
+    assert_close(res[5][0], res[0][0], 3e-5, "wino2axis-vs-direct.dw")
 
 
 @pytest.mark.parametrize("B,Cin,Cout,sp", [(2, 3, 64, (4, 6, 7)), (1, 64, 64, (3, 4, 7)), (2, 64, 64, (7, 12))])
@@ -748,34 +755,37 @@ def test_full_size_weight_gradient_by_supports_and_kernels(ops):
     wshape = (C, C, 3, 3, 3)
     prev = lib.hpvg_conv_bwd_weight_wino_config(-1)
     try:
-        assert lib.hpvg_conv_bwd_weight_wino_config(2) == 2
-        for (t0, t1, h0, h1, w0, w1) in [(0, 2, 0, 5, 0, 7), (5, 8, 68, 75, 125, 135), (11, 13, 139, 144, 249, 256)]:
-            dy = torch.zeros(B, C, T, H, W, device=DEV)
-            blk = torch.randn(C, t1 - t0, h1 - h0, w1 - w0, device=DEV, generator=g)
-            dy[1, :, t0:t1, h0:h1, w0:w1] = blk
-            dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
-            assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
-            ts, hs, ws_ = max(t0 - 1, 0), max(h0 - 1, 0), max(w0 - 1, 0)
-            te, he, we = min(t1 + 1, T), min(h1 + 1, H), min(w1 + 1, W)
-            xc = x[1:2, :, ts:te, hs:he, ws_:we].cpu()
-            dyc = torch.zeros(1, C, te - ts, he - hs, we - ws_)
-            dyc[0, :, t0 - ts:t1 - ts, h0 - hs:h1 - hs, w0 - ws_:w1 - ws_] = blk.cpu()
-            wz = torch.zeros(wshape, requires_grad=True)
-            (want,) = torch.autograd.grad(O.conv(xc, wz, None), wz, dyc)
-            assert_close(dw, want, RTOL, "fullsize.wgrad.support(%d,%d,%d)" % (t0, h0, w0))
-            assert_close(db, blk.cpu().sum(dim=(1, 2, 3)), 1e-5, "fullsize.bgrad.support(%d,%d,%d)" % (t0, h0, w0))
+        for smode in (2, 5):    # the one-axis and the two-axis Winograd kernel (5: conv_wgradw2_kernel, W = 256)
+            assert lib.hpvg_conv_bwd_weight_wino_config(smode) == smode
+            assert lib.hpvg_conv_bwd_weight_kernel_kind(B, C, C, T, H, W, 3) == (3 if smode == 5 else 2)
+            for (t0, t1, h0, h1, w0, w1) in [(0, 2, 0, 5, 0, 7), (5, 8, 68, 75, 125, 135), (11, 13, 139, 144, 249, 256)]:
+                dy = torch.zeros(B, C, T, H, W, device=DEV)
+                blk = torch.randn(C, t1 - t0, h1 - h0, w1 - w0, device=DEV, generator=g)
+                dy[1, :, t0:t1, h0:h1, w0:w1] = blk
+                dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
+                assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
+                ts, hs, ws_ = max(t0 - 1, 0), max(h0 - 1, 0), max(w0 - 1, 0)
+                te, he, we = min(t1 + 1, T), min(h1 + 1, H), min(w1 + 1, W)
+                xc = x[1:2, :, ts:te, hs:he, ws_:we].cpu()
+                dyc = torch.zeros(1, C, te - ts, he - hs, we - ws_)
+                dyc[0, :, t0 - ts:t1 - ts, h0 - hs:h1 - hs, w0 - ws_:w1 - ws_] = blk.cpu()
+                wz = torch.zeros(wshape, requires_grad=True)
+                (want,) = torch.autograd.grad(O.conv(xc, wz, None), wz, dyc)
+                assert_close(dw, want, RTOL, "fullsize.wgrad.mode%d.support(%d,%d,%d)" % (smode, t0, h0, w0))
+                assert_close(db, blk.cpu().sum(dim=(1, 2, 3)), 1e-5, "fullsize.bgrad.mode%d.support(%d,%d,%d)" % (smode, t0, h0, w0))
         dy = torch.randn(B, C, T, H, W, device=DEV, generator=g)
         res = {}
-        for mode in (2, 4, 3, 0):
+        for mode in (2, 4, 3, 5, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
             res[mode] = ops.conv_bwd_weight_raw(dy, x, wshape)
-        for mode in (2, 4, 3):
+        for mode in (2, 4, 3, 5):
             assert_close(res[mode], res[0], 3e-5, "fullsize.wgrad.mode%d-vs-direct" % mode)
-        assert lib.hpvg_conv_bwd_weight_wino_config(2) == 2
-        dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
-        assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
-        assert torch.equal(dw, res[2])
-        assert_close(db, dy.double().sum(dim=(0, 2, 3, 4)).float(), 1e-5, "fullsize.bgrad", atol=2e-2)
+        for mode in (2, 5):
+            assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
+            dw, db = torch.zeros(wshape, device=DEV), torch.zeros(C, device=DEV)
+            assert ops.conv_bwd_weight_bias_raw(dy, x, wshape, dw, db)
+            assert torch.equal(dw, res[mode])
+            assert_close(db, dy.double().sum(dim=(0, 2, 3, 4)).float(), 1e-5, "fullsize.bgrad", atol=2e-2)
     finally:
         lib.hpvg_conv_bwd_weight_wino_config(prev)
 

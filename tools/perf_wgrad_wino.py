@@ -35,11 +35,13 @@ for st in stages:
     wshape = (64, 64) + (3,) * dims
     flops = 2.0 * B * 64 * 64 * (27 if dims == 3 else 9) * x[0, 0].numel()
     row, out = {}, {}
-    for mode in (0, 2):
+    for mode in (0, 2, 5):
         lib.hpvg_conv_bwd_weight_wino_config(mode)
         row[mode] = bench(lambda: ops.conv_bwd_weight_raw(dy, x, wshape))
         out[mode] = ops.conv_bwd_weight_raw(dy, x, wshape)
     err = float((out[2] - out[0]).abs().max() / out[0].abs().max())
-    print("stage %d %s B=%d  direct %.4f ms | wino %.4f ms | x%.3f | wino %.1f TFLOP/s (algorithmic) | rel diff %.2e"
-          % (st, sp, B, row[0], row[2], row[0] / row[2], flops / row[2] / 1e9, err), flush=True)
+    err5 = float((out[5] - out[0]).abs().max() / out[0].abs().max())
+    kind5 = lib.hpvg_conv_bwd_weight_kernel_kind(B, 64, 64, T if dims == 3 else 1, H, W, 3 if dims == 3 else 1)
+    print("stage %d %s B=%d  direct %.4f ms | wino %.4f ms | x%.3f | wino %.1f TFLOP/s (algorithmic) | rel diff %.2e | two-axis(kind %d) %.4f ms x%.3f over one-axis, %.1f TFLOP/s, rel diff %.2e"
+          % (st, sp, B, row[0], row[2], row[0] / row[2], flops / row[2] / 1e9, err, kind5, row[5], row[2] / row[5], flops / row[5] / 1e9, err5), flush=True)
 lib.hpvg_conv_bwd_weight_wino_config(1)
