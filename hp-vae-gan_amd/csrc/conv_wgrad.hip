@@ -1572,21 +1572,23 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       hipStream_t s = (hipStream_t)stream;
       const dim3 grid((KT == 3 ? 2 * p2.S0 + p2.S : p2.S) * p2.nob * p2.ncb);
       const int gjd = hpvg_cdiv(p2.Th * (p2.Tw / 4), 64), gjx = hpvg_cdiv((p2.Th + 2) * (p2.Tw / 4 + 2), 64);
-#define HPVG_W2_LAUNCH(K, D, X)                                                                                        \
+#define HPVG_W2_LAUNCH(K, D, X, TWC)                                                                                   \
   {                                                                                                                    \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw2_kernel<K, D, X>),                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw2_kernel<K, D, X, TWC>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
         (void)hipGetLastError();                                                                                       \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X>), grid, dim3(256), p2.lds, s, a);                                 \
+    hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X, TWC>), grid, dim3(256), p2.lds, s, a);                            \
   }
+      // (the 16-column band - the tile of the large launches - has its row strides as immediates: one address register per operand)
 #define HPVG_W2_PICK(K)                                                                                                \
-  if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1)                                                                    \
-  else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2)                                                                           \
-  else HPVG_W2_LAUNCH(K, 2, 2)
+  if (gjd == 1 && gjx == 1 && p2.Tw == 16) HPVG_W2_LAUNCH(K, 1, 1, 16)                                                 \
+  else if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1, 0)                                                            \
+  else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2, 0)                                                                        \
+  else HPVG_W2_LAUNCH(K, 2, 2, 0)
       if (KT == 3) {
         HPVG_W2_PICK(3)
       } else {

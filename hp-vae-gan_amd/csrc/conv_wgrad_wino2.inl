@@ -30,7 +30,7 @@
 // a.order: the walk over the tiles.  0: time-major (tile = ((b * nth + th) * ntw + tw) * T + t: the slots of an XCD hold one
 // spatial tile at neighbouring t); 1: plane-major (tile = ((b * T + t) * nth + th) * ntw + tw: the slots of an XCD hold
 // neighbouring tiles of one plane, which share halo columns / rows and the other halves of their 128-byte lines in that XCD's L2)
-template <int KT, int NJD, int NJX>
+template <int KT, int NJD, int NJX, int TWC>
 __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NW = 4, NT = 256, NCH = 16, LW = 64, PW = 256;
@@ -196,7 +196,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     float* bufc = lds + cur * BUF;
     cnext = NCH;
     if (have_next) {
+#ifdef HPVG_ABLW2_NOSETUP   // (development ablation, timing only: every tile stages the first one again, the set-up hoisted)
+      setup(slot);
+#else
       setup(next);
+#endif
       dma_begin(lds + (cur ^ 1) * BUF);
       cnext = 0;
     }
@@ -207,109 +211,134 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 #endif
       // this lane's quad of step st: quad 2 st + half of the tile's row-major quad index (Tw / 2 quads per quad row, an even
       // count: both halves of a step sit in the same quad row)
+      // VALU instructions do NOT run in the shadow of an fp32 MFMA (tools/mfma_fillers.hip: v_mfma_f32_32x32x2_f32 and the
+      // vector ALU share the fp32 datapath - every v_add / v_mov between two MFMAs adds its 4-5 cycles to the 64; LDS reads and
+      // scalar instructions are free), so the K step is written for the fewest vector instructions: packed transforms
+      // (v_pk_add_f32 on the 8-byte pairs as they come from LDS: 22 per step), operands consumed where they are produced (no
+      // copies: two register sets A / B), one address register per operand (TWC: the row strides are immediates).
       const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
       const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half + 4;
       int dyo = 0, xo = 0, wc = 0, ls = 0;   // offsets of the step being LOADED (steps are loaded in order, then wrap)
-      wf32x2a ry[2], rx[4][2];           // raw operands of the next step
-      float tn[4][4], rv[4][2];
-      float yA[16], vA[16], yB[16], vB[16];
-#define WG2_LOAD()                                                                          \
+      wf32x2a rx[4][2] = {};                  // raw input patch of the next step: rx[row][pair]
+      // per register set: the dY quad rows ry[0..1] (also points (0, 0/3) and (3, 0/3)), their sum / difference rv1, rv2 (rows
+      // 1, 2: points (i, 0/3)), y12[i] = points (i, 1), (i, 2); v03[i] = points (i, 0), (i, 3), v12[i] = (i, 1), (i, 2)
+      wf32x2a ryA[2] = {}, rv1A, rv2A, y12A[4], v03A[4], v12A[4];
+      wf32x2a ryB[2] = {}, rv1B, rv2B, y12B[4], v03B[4], v12B[4];
+      const int TwR = TWC > 0 ? TWC : Tw, RSR = TWC > 0 ? TWC + 8 : RS;
+#ifdef HPVG_ABLW2_NOLDS
+#define WG2_LOAD(RY) { if (++ls == nsteps) ls = 0; }
+#else
+#define WG2_LOAD(RY)                                                                        \
   {                                                                                         \
-    ry[0] = *reinterpret_cast<const wf32x2a*>(dl + dyo);                                    \
-    ry[1] = *reinterpret_cast<const wf32x2a*>(dl + dyo + Tw);                               \
+    RY[0] = *reinterpret_cast<const wf32x2a*>(dl + dyo);                                    \
+    RY[1] = *reinterpret_cast<const wf32x2a*>(dl + dyo + TwR);                              \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                      \
-      rx[r_][0] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RS);                     \
-      rx[r_][1] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RS + 2);                 \
+      rx[r_][0] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RSR);                    \
+      rx[r_][1] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RSR + 2);                \
     }                                                                                       \
     dyo += 4;                                                                               \
     xo += 4;                                                                                \
-    if (++wc == gpr) { wc = 0; dyo += Tw; xo += 2 * RS - Tw; }                              \
-    if (++ls == nsteps) { ls = 0; wc = 0; dyo = 0; xo = 0; }                                \
+    const bool roww_ = ++wc == gpr;                                                         \
+    wc = roww_ ? 0 : wc;                                                                    \
+    dyo += roww_ ? TwR : 0;                                                                 \
+    xo += roww_ ? 2 * RSR - TwR : 0;                                                        \
+    const bool tilew_ = ++ls == nsteps;                                                     \
+    ls = tilew_ ? 0 : ls;                                                                   \
+    wc = tilew_ ? 0 : wc;                                                                   \
+    dyo = tilew_ ? 0 : dyo;                                                                 \
+    xo = tilew_ ? 0 : xo;                                                                   \
   }
-// vertical pass of the dY quad: rv[i][s] = (A' y)[i][s]
-#define WG2_YV()                                                                            \
+#endif
+// (lo, hi) -> (src.lo + oth.hi, src.lo - oth.hi): the two middle points of a row from its pairs
+#define WG2_MID(S, O) (__builtin_shufflevector(S, S, 0, 0) + __builtin_shufflevector(O, O, 1, 1) * wf32x2a{1.f, -1.f})
+#ifdef HPVG_ABLW2_NOXF
+#define WG2_YXF(RY, RV1, RV2, Y12) { RV1 = RY[0]; RV2 = RY[1]; Y12[0] = RY[0]; Y12[1] = RY[1]; Y12[2] = RY[0]; Y12[3] = RY[1]; }
+#define WG2_XV() {}
+#define WG2_XH(I, V03, V12) { V03[I] = rx[I][0]; V12[I] = rx[I][1]; }
+#else
+// dY quad: vertical pass rv1 = row0 + row1, rv2 = row0 - row1 (rows 0 / 3 are the raw rows), then per row P = (p0, p1) the
+// points (P.lo, P.lo + P.hi, P.lo - P.hi, P.hi)
+#define WG2_YXF(RY, RV1, RV2, Y12)                                                          \
   {                                                                                         \
-    rv[0][0] = ry[0][0]; rv[0][1] = ry[0][1];                                               \
-    rv[1][0] = ry[0][0] + ry[1][0]; rv[1][1] = ry[0][1] + ry[1][1];                         \
-    rv[2][0] = ry[0][0] - ry[1][0]; rv[2][1] = ry[0][1] - ry[1][1];                         \
-    rv[3][0] = ry[1][0]; rv[3][1] = ry[1][1];                                               \
+    RV1 = RY[0] + RY[1];                                                                    \
+    RV2 = RY[0] - RY[1];                                                                    \
+    Y12[0] = WG2_MID(RY[0], RY[0]);                                                         \
+    Y12[1] = WG2_MID(RV1, RV1);                                                             \
+    Y12[2] = WG2_MID(RV2, RV2);                                                             \
+    Y12[3] = WG2_MID(RY[1], RY[1]);                                                         \
   }
-// horizontal pass of row I: Y[I][*]
-#define WG2_YH(I, Y)                                                                        \
+// input patch, vertical pass on the column pairs: tn[i][pair] = (B^T d)[i][2 pair .. 2 pair + 1]
+#define WG2_XV()                                                                            \
   {                                                                                         \
-    Y[(I) * 4 + 0] = rv[I][0];                                                              \
-    Y[(I) * 4 + 1] = rv[I][0] + rv[I][1];                                                   \
-    Y[(I) * 4 + 2] = rv[I][0] - rv[I][1];                                                   \
-    Y[(I) * 4 + 3] = rv[I][1];                                                              \
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                      \
+      tn[0][p_] = rx[0][p_] - rx[2][p_];                                                    \
+      tn[1][p_] = rx[1][p_] + rx[2][p_];                                                    \
+      tn[2][p_] = rx[2][p_] - rx[1][p_];                                                    \
+      tn[3][p_] = rx[1][p_] - rx[3][p_];                                                    \
+    }                                                                                       \
   }
-// vertical pass of patch column C: tn[i][C] = (B^T d)[i][C]
-#define WG2_XV(C)                                                                           \
+// horizontal pass of row I: A = tn[I][0] = (t0, t1), B = tn[I][1] = (t2, t3): (V0, V3) = A - B, (V1, V2) = (t2 + t1, t2 - t1)
+#define WG2_XH(I, V03, V12)                                                                 \
   {                                                                                         \
-    const float d0_ = rx[0][(C) >> 1][(C) & 1], d1_ = rx[1][(C) >> 1][(C) & 1];             \
-    const float d2_ = rx[2][(C) >> 1][(C) & 1], d3_ = rx[3][(C) >> 1][(C) & 1];             \
-    tn[0][C] = d0_ - d2_; tn[1][C] = d1_ + d2_; tn[2][C] = d2_ - d1_; tn[3][C] = d1_ - d3_; \
+    V03[I] = tn[I][0] - tn[I][1];                                                           \
+    V12[I] = WG2_MID(tn[I][1], tn[I][0]);                                                   \
   }
-// horizontal pass of row I: V[I][*]
-#define WG2_XH(I, V)                                                                        \
+#endif
+      wf32x2a tn[4][2];
+#define WG2_TRANSFORM(RY, RV1, RV2, Y12, V03, V12)                                          \
   {                                                                                         \
-    V[(I) * 4 + 0] = tn[I][0] - tn[I][2];                                                   \
-    V[(I) * 4 + 1] = tn[I][1] + tn[I][2];                                                   \
-    V[(I) * 4 + 2] = tn[I][2] - tn[I][1];                                                   \
-    V[(I) * 4 + 3] = tn[I][1] - tn[I][3];                                                   \
-  }
-#define WG2_TRANSFORM(Y, V)                                                                 \
-  {                                                                                         \
-    WG2_YV() WG2_XV(0) WG2_XV(1) WG2_XV(2) WG2_XV(3)                                        \
-    WG2_XH(0, V) WG2_XH(1, V) WG2_XH(2, V) WG2_XH(3, V)                                     \
-    WG2_YH(0, Y) WG2_YH(1, Y) WG2_YH(2, Y) WG2_YH(3, Y)                                     \
+    WG2_YXF(RY, RV1, RV2, Y12) WG2_XV()                                                     \
+    WG2_XH(0, V03, V12) WG2_XH(1, V03, V12) WG2_XH(2, V03, V12) WG2_XH(3, V03, V12)         \
   }
 #ifdef HPVG_ABLW2_NODMA
 #define WG2_DMA(Q) { if (cnext < NCH && (Q) == NP - 1) ++cnext; }
 #else
 #define WG2_DMA(Q) dma_piece(Q);
 #endif
-// slot K of a step of parity SP: one MFMA on the current operands (YC, VC) + a unit of the next step's preparation (into YN, VN)
-#define WG2_SLOT(SP, K, YC, VC, YN, VN, MORE)                                                                      \
+// operands of point K = 4 i + j out of a register set
+#define WG2_YOP(K, RY, RV1, RV2, Y12)                                                                              \
+  (((K) & 3) == 0 ? ((K) >> 2 == 0 ? RY[0][0] : ((K) >> 2 == 1 ? RV1[0] : ((K) >> 2 == 2 ? RV2[0] : RY[1][0])))     \
+   : ((K) & 3) == 3 ? ((K) >> 2 == 0 ? RY[0][1] : ((K) >> 2 == 1 ? RV1[1] : ((K) >> 2 == 2 ? RV2[1] : RY[1][1])))  \
+   : Y12[(K) >> 2][((K) & 3) - 1])
+#define WG2_VOP(K, V03, V12) (((K) & 3) == 0 ? V03[(K) >> 2][0] : (((K) & 3) == 3 ? V03[(K) >> 2][1] : V12[(K) >> 2][((K) & 3) - 1]))
+// slot K of a step of parity SP: one MFMA on the current set (C) + a unit of the next step's preparation (into set N)
+#define WG2_SLOT(SP, K, C, N)                                                                                      \
   {                                                                                                                \
-    acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(YC[K], VC[K], acc[K], 0, 0, 0);                                  \
-    if ((K) == 0) bsum = __builtin_fmaf(bflag, YC[5], bsum);                                                       \
-    if (MORE) {                                                                                                    \
-      if ((K) == 0) WG2_LOAD()                                                                                     \
-      if ((K) == 3) WG2_YV()                                                                                       \
-      if ((K) >= 4 && (K) < 8) WG2_XV((K) & 3)                                                                     \
-      if ((K) >= 8 && (K) < 12) WG2_XH((K) & 3, VN)                                                                \
-      if ((K) >= 12) WG2_YH((K) & 3, YN)                                                                           \
-    }                                                                                                              \
+    acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(WG2_YOP(K, ry##C, rv1##C, rv2##C, y12##C), WG2_VOP(K, v03##C, v12##C), acc[K], 0, 0, 0); \
+    if ((K) == 0) bsum = __builtin_fmaf(bflag, y12##C[1][0], bsum);                                                \
+    if ((K) == 0) WG2_LOAD(ry##N)                                                                                  \
+    if ((K) == 4) WG2_XV()                                                                                         \
+    if ((K) >= 6 && (K) < 10) WG2_XH(((K) - 6) & 3, v03##N, v12##N)                                                      \
+    if ((K) == 11) WG2_YXF(ry##N, rv1##N, rv2##N, y12##N)                                                          \
     if (((K) & 3) == 1 && ((K) >> 2) < PS) WG2_DMA(((SP) * PS + ((K) >> 2)) % NP)                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
-#define WG2_STEP(SP, YC, VC, YN, VN, MORE)                                                                         \
+#define WG2_STEP(SP, C, N)                                                                                         \
   {                                                                                                                \
-    WG2_SLOT(SP, 0, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 1, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 2, YC, VC, YN, VN, MORE)    \
-    WG2_SLOT(SP, 3, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 4, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 5, YC, VC, YN, VN, MORE)    \
-    WG2_SLOT(SP, 6, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 7, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 8, YC, VC, YN, VN, MORE)    \
-    WG2_SLOT(SP, 9, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 10, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 11, YC, VC, YN, VN, MORE)  \
-    WG2_SLOT(SP, 12, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 13, YC, VC, YN, VN, MORE) WG2_SLOT(SP, 14, YC, VC, YN, VN, MORE) \
-    WG2_SLOT(SP, 15, YC, VC, YN, VN, MORE)                                                                         \
+    WG2_SLOT(SP, 0, C, N) WG2_SLOT(SP, 1, C, N) WG2_SLOT(SP, 2, C, N) WG2_SLOT(SP, 3, C, N)                        \
+    WG2_SLOT(SP, 4, C, N) WG2_SLOT(SP, 5, C, N) WG2_SLOT(SP, 6, C, N) WG2_SLOT(SP, 7, C, N)                        \
+    WG2_SLOT(SP, 8, C, N) WG2_SLOT(SP, 9, C, N) WG2_SLOT(SP, 10, C, N) WG2_SLOT(SP, 11, C, N)                      \
+    WG2_SLOT(SP, 12, C, N) WG2_SLOT(SP, 13, C, N) WG2_SLOT(SP, 14, C, N) WG2_SLOT(SP, 15, C, N)                    \
   }
-      // first step's operands (nothing to hide them behind), then two steps per iteration: A -> B -> A.  ONE loop body holds
-      // every MFMA of the kernel (nsteps is even: the planner's tiles have Th * Tw % 16 == 0): hipcc gives the accumulators of a
-      // peeled step other registers and copies / spills all 256 around it.  The last step therefore prepares operands as well
-      // (WG2_LOAD wraps to the tile's first step: in-bounds reads whose results are dropped).
-      WG2_LOAD()
-      WG2_TRANSFORM(yA, vA)
+      // first step's operands, then two steps per iteration: A -> B -> A.  ONE loop body holds every MFMA of the kernel
+      // (nsteps is even: the planner's tiles have Th * Tw % 16 == 0): hipcc gives the accumulators of a peeled step other
+      // registers and copies / spills all 256 around it.  The last step therefore prepares operands as well (WG2_LOAD wraps to
+      // the tile's first step: in-bounds reads whose results are dropped).
+      WG2_LOAD(ryA)
+      WG2_TRANSFORM(ryA, rv1A, rv2A, y12A, v03A, v12A)
       for (int st = 0; st < nsteps; st += 2) {
-        WG2_STEP(0, yA, vA, yB, vB, true)
-        WG2_STEP(1, yB, vB, yA, vA, true)
+        WG2_STEP(0, A, B)
+        WG2_STEP(1, B, A)
       }
 #undef WG2_STEP
 #undef WG2_SLOT
+#undef WG2_VOP
+#undef WG2_YOP
 #undef WG2_DMA
 #undef WG2_TRANSFORM
 #undef WG2_XH
 #undef WG2_XV
-#undef WG2_YH
-#undef WG2_YV
+#undef WG2_YXF
+#undef WG2_MID
 #undef WG2_LOAD
     }
     {   // this tile's bias sum into the running one (Kahan)
