@@ -1307,9 +1307,12 @@ inline size_t wgradw2_slab_bytes(const WPlan& p, int KT) { return (size_t)p.S * 
 inline size_t wgradw2_ws_bytes(const WPlan& p, int KT) { return 256 + wgradw2_slab_bytes(p, KT) + (size_t)p.S * p.nob * 64 * sizeof(float); }
 // Where the two-axis kernel is taken.  g_wgradw2: 0 = by size, 1 = never, 2 = wherever it can run (HPVG_WGRADW2 at start;
 // hpvg_conv_bwd_weight_wino_config modes 5 / 6 set 2 / 1).  By size: a workgroup must walk enough tiles to amortise its larger
-// slab (16 instead of 12 point tiles) and reduce: measured on MI355X (tools/perf_wgrad_wino.py), see DESIGN.md.
+// slab (16 instead of 12 point tiles per block) and reduce.  Measured on MI355X against the one-axis kernel (tools/ab_wgrad2_sizes.sh,
+// profiles/r03_ab_wgrad2_sizes.txt; 64 -> 64, tiles per persistent workgroup of the centre tap): 3x3x3: 1.4 tiles x0.99, 2.8
+// x1.06, 4.1 x1.14, 13 x1.31, 53 x1.38, 117 x1.42; 3x3 (three times the workgroups per launch, a third of the work each):
+// 2 x0.89, 4 x1.02, 5.3 x1.01, 6 x1.08, 8 x1.17.  HPVG_WGRADW2_MIN_TILES overrides both thresholds.
 int g_wgradw2 = -1;
-long g_wgradw2_min_tiles = 24;    // tiles per persistent workgroup from which the two-axis kernel is taken by default
+long g_wgradw2_min_tiles = -1;    // tiles per persistent workgroup from which the two-axis kernel is taken (default: 2 / 5 for 3-D / 2-D)
 inline bool wgradw2_wanted(const WPlan& p2, int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (g_wgradw2 < 0) {
     const char* e = getenv("HPVG_WGRADW2");
@@ -1321,7 +1324,8 @@ inline bool wgradw2_wanted(const WPlan& p2, int B, int Cin, int Cout, int T, int
   if (!wgradw_wanted(p2, B, Cin, Cout, T, H, W, KT)) return false;     // (the Winograd weight gradient switched off altogether)
   if (g_wgradw2 == 2) return true;
   const long ntiles = (long)B * T * p2.nth * p2.ntw;
-  return ntiles >= g_wgradw2_min_tiles * (long)p2.S;
+  const long mt = g_wgradw2_min_tiles >= 0 ? g_wgradw2_min_tiles : (KT == 3 ? 2 : 5);
+  return ntiles >= mt * (long)p2.S;
 }
 
 // tile plan of conv_wgrad3_kernel: the same tile family as conv_wgrad_kernel under its own LDS budget (two dY tiles, four

@@ -8,6 +8,9 @@ import hp_vae_gan_amd
 from hp_vae_gan_amd import ops, lib as hplib
 
 SHAPES = {0: (4, 18, 33), 1: (4, 23, 41), 2: (4, 29, 52), 3: (5, 36, 65), 4: (5, 45, 81), 5: (5, 57, 102), 6: (7, 72, 129), 7: (7, 91, 162), 8: (7, 114, 204), 9: (13, 144, 256)}
+# HPVG_PERF_SHAPES="T,H,W;T,H,W;..." adds shapes as stages 100, 101, ...
+for k, spec in enumerate(filter(None, os.environ.get("HPVG_PERF_SHAPES", "").split(";"))):
+    SHAPES[100 + k] = tuple(int(v) for v in spec.split(","))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 stages = [int(a) for a in sys.argv[2:]] or list(range(10))
 B = int(os.environ.get("HPVG_PERF_B", "2"))
