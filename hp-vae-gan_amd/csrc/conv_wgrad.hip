@@ -1571,7 +1571,7 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       a.Th = p2.Th; a.Tw = p2.Tw; a.RS = p2.RS; a.DS = p2.DS; a.XS = p2.XS; a.QK = p2.QK; a.nth = p2.nth; a.ntw = p2.ntw;
       a.S = p2.S; a.S0 = p2.S0; a.ncb = p2.ncb; a.nob = p2.nob; a.in_lrelu = 0;
       a.bpart = db ? (float*)((char*)ws + 256 + wgradw2_slab_bytes(p2, KT)) : nullptr;
-      static const int order_env = [] { const char* e = getenv("HPVG_WG2_ORDER"); return e ? atoi(e) : 0; }();
+      static const int order_env = [] { const char* e = getenv("HPVG_WG2_ORDER"); return e ? atoi(e) : 1; }();   // plane-major: same time, 1.9 instead of 3.4 GB of HBM traffic per stage-9 launch (profiles/r03_ab_wgrad2_order.txt)
       a.order = order_env;
       hipStream_t s = (hipStream_t)stream;
       const dim3 grid((KT == 3 ? 2 * p2.S0 + p2.S : p2.S) * p2.nob * p2.ncb);
