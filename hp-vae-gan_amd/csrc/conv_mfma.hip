@@ -560,6 +560,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
 
 #include "conv_wino.inl"
 #include "conv_wino2d.inl"
+#include "conv_wino2r.inl"
 
 // ------------------------------------------------------------------------------------------
 // Narrow-output convolution (Cout <= 4): the tails 64->3 / 64->1 (networks_3d.py:175,341,362) and the backward-data
@@ -1311,10 +1312,13 @@ inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
   return rounds >= 3 && (double)q.ntl >= 0.88 * (double)(rounds * HPVG_NUM_CU);
 }
+// HPVG_WINO2R=0 keeps the first-generation kernel (every wave all 16 points of one block: conv_wino2d_kernel); default: the
+// points split over the waves by row (conv_wino2r_kernel: half the input-transform instructions and U loads per MFMA)
+static const bool g_wino2r = [] { const char* e = getenv("HPVG_WINO2R"); return !e || atoi(e) != 0; }();
 template <int VAR, bool TAIL>
 int launch_wino2d_inst(const Wino2Args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_wino2d_kernel<VAR, TAIL>;
+  auto kern = g_wino2r ? conv_wino2r_kernel<VAR, TAIL> : conv_wino2d_kernel<VAR, TAIL>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       (void)hipGetLastError();
