@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     const int lo = (2 * R0 - 1) * W + 2 * c0 - 1;               // first input element of the tile (odd)
     return lo >= 0 ? (lo & ~3) : -((3 - lo) & ~3);
   };
-  struct StageT { int b, t; unsigned voff; bool ok; int tail; };
+  struct StageT { int b, t; unsigned voff; bool ok, zl; unsigned long long okm; bool anyz; int tail; };
   auto stage_setup = [&](int tile) __attribute__((always_inline)) -> StageT {
     StageT q;
     int tp, yb;
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     const int i0 = lo4 + 4 * tid;
     q.ok = tid < ng && i0 >= 0 && i0 + 4 <= HWp;                 // a group is loaded when it lies wholly inside the plane
     q.voff = q.ok ? (unsigned)i0 * 4u : 0u;
+    // lanes of the span that lie outside the plane (image rows above / below): never loaded (EXEC), their LDS words are zeroed
+    // by the lane itself when the item is staged; lanes past the span are never read
+    q.zl = tid < ng && !q.ok;
+    q.okm = __builtin_amdgcn_ballot_w64(q.ok);
+    q.anyz = __builtin_amdgcn_ballot_w64(q.zl) != 0ull;
     const int gt = (HWp - lo4) >> 2;
     q.tail = TAIL ? __builtin_amdgcn_readfirstlane(gt < ng ? gt : -1) : -1;   // uniform: keep it scalar
     return q;
@@ -144,21 +149,42 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     c_w = 2 * (Q - Rq * a.Cq);
   };
   const long THWb = (long)a.T * HWb;
+  unsigned vzero = 0u;
+  asm volatile("" : "+v"(vzero));                    // a zero offset that lives in a vector register (the zero-plane pieces)
+  // the LDS words of this lane's group in the 12 plane slots of buffer bf := 0, for the lanes of the span outside the plane
+  // (only tiles at the top / bottom of a plane have any: a wave-uniform test first)
+  auto stage_zero = [&](const StageT& q, int bf) __attribute__((always_inline)) {
+    if (q.anyz) {
+      if (q.zl) {
+        float* dst = xs + bf * BUFF + 1 + 4 * tid;
+#pragma unroll
+        for (int pl = 0; pl < 12; ++pl) {
+          dst[pl * PL + 0] = 0.f; dst[pl * PL + 1] = 0.f; dst[pl * PL + 2] = 0.f; dst[pl * PL + 3] = 0.f;
+        }
+      }
+    }
+  };
   auto plane0 = [&](const StageT& q, int sc) __attribute__((always_inline)) -> const char* {
     return reinterpret_cast<const char*>(a.x) + (((long)q.b * a.Cin + (long)sc * 4) * a.T + (q.t - 1)) * HWb;
   };
 
-  // raw rows of the next step's two patches: ra_[qh][pair], rb_[qh][pair]; XA / XB: this lane's row pointers (8-byte units)
+  // raw rows of the next step's two patches: rwa[qh][pair], rwb[qh][pair]; XA / XB: this lane's LDS byte addresses of its rows.
+  // Hand-written ds_read_b64 with the plane offset as a 16-bit immediate (hipcc merges the two pairs of a row into one
+  // ds_read2_b64, whose 8-bit offsets do not reach the plane slots: a vector add per row and step - and vector instructions are
+  // what this kernel pays for); LDS reads issue in the MFMAs' shadow.  W2R_WAIT_RAW before the first use (form (ii) of
+  // cdna_hip_programming.md 5.7: the destinations pass through the wait statement).
+#define W2R_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W2R_LOAD_RAW(XA, XB, STEP)                                                              \
   {                                                                                             \
-    const int so_ = (((STEP) & 1) * 6 + ((STEP) >> 1)) * (PL / 2);                              \
-    _Pragma("unroll") for (int qh_ = 0; qh_ < 2; ++qh_) {                                       \
-      rwa[qh_][0] = (XA)[qh_][so_];                                                             \
-      rwa[qh_][1] = (XA)[qh_][so_ + 1];                                                         \
-      rwb[qh_][0] = (XB)[qh_][so_];                                                             \
-      rwb[qh_][1] = (XB)[qh_][so_ + 1];                                                         \
-    }                                                                                           \
+    constexpr int so_ = (((STEP) & 1) * 6 + ((STEP) >> 1)) * (PL / 2) * 8;                      \
+    W2R_DSREAD(rwa[0][0], (XA)[0], so_); W2R_DSREAD(rwa[0][1], (XA)[0], so_ + 8);               \
+    W2R_DSREAD(rwb[0][0], (XB)[0], so_); W2R_DSREAD(rwb[0][1], (XB)[0], so_ + 8);               \
+    W2R_DSREAD(rwa[1][0], (XA)[1], so_); W2R_DSREAD(rwa[1][1], (XA)[1], so_ + 8);               \
+    W2R_DSREAD(rwb[1][0], (XB)[1], so_); W2R_DSREAD(rwb[1][1], (XB)[1], so_ + 8);               \
   }
+#define W2R_WAIT_RAW()                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rwa[0][0]), "+v"(rwa[0][1]), "+v"(rwa[1][0]), "+v"(rwa[1][1]),  \
+               "+v"(rwb[0][0]), "+v"(rwb[0][1]), "+v"(rwb[1][0]), "+v"(rwb[1][1]))
 // vertical pass of row ri, columns 2 P, 2 P + 1 of quad half QH
 #define W2R_VERT(QH, P)                                                                         \
   {                                                                                             \
@@ -196,17 +222,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       const int cc = pl / 3, dt = pl - 3 * cc;
       const int tt = st_cur.t + dt - 1;
       const bool pok = cc < a.Cin && tt >= 0 && tt < a.T;
-      const char* src = (pok && st_cur.ok) ? p0 + ((long)cc * THWb + (long)dt * HWb) + st_cur.voff : zero_ptr;
-      w2_dma16(src, lds0 + (unsigned)((pl * PL + 1) * 4 + wave * 1024));
+      const unsigned dst = lds0 + (unsigned)((pl * PL + 1) * 4 + wave * 1024);
+      if (pok) conv_dma_piece16(p0 + ((long)cc * THWb + (long)dt * HWb), st_cur.voff, dst, st_cur.okm);
+      else conv_dma_piece16(zero_ptr, vzero, dst, ~0ull);
     }
+    stage_zero(st_cur, 0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if constexpr (TAIL) stage_tail(st_cur, 0, 0);
   asm volatile("s_barrier" ::: "memory");
   {
-    const f32x2a* xa0[2] = {reinterpret_cast<const f32x2a*>(xs + rd_cur.ba[0]), reinterpret_cast<const f32x2a*>(xs + rd_cur.ba[1])};
-    const f32x2a* xb0[2] = {reinterpret_cast<const f32x2a*>(xs + rd_cur.bb[0]), reinterpret_cast<const f32x2a*>(xs + rd_cur.bb[1])};
+    const unsigned xa0[2] = {lds0 + (unsigned)rd_cur.ba[0] * 4u, lds0 + (unsigned)rd_cur.ba[1] * 4u};
+    const unsigned xb0[2] = {lds0 + (unsigned)rd_cur.bb[0] * 4u, lds0 + (unsigned)rd_cur.bb[1] * 4u};
     W2R_LOAD_RAW(xa0, xb0, 0)
+    W2R_WAIT_RAW();
     W2R_VERT(0, 0) W2R_VERT(0, 1) W2R_VERT(1, 0) W2R_VERT(1, 1)
     W2R_HORZ(0, 0, vA, rd_cur.f0, rd_cur.f3) W2R_HORZ(0, 1, vA, rd_cur.f0, rd_cur.f3)
     W2R_HORZ(1, 0, vA, rd_cur.f0, rd_cur.f3) W2R_HORZ(1, 1, vA, rd_cur.f0, rd_cur.f3)
@@ -224,8 +253,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     cmp_setup(tile);
     const char* abase_cur = reinterpret_cast<const char*>(a.wp) + ((long)((tile % a.gridy) * 2)) * 1024 + (long)ri * afrag;
     const char* abase_nxt = reinterpret_cast<const char*>(a.wp) + ((long)((ntile % a.gridy) * 2)) * 1024 + (long)ri * afrag;
-    const char* lane0_cur = plane0(st_cur, 0) + st_cur.voff;
-    const char* lane0_nxt = plane0(st_nxt, 0) + st_nxt.voff;
     float f0[2] = {rd_cur.f0[0], rd_cur.f0[1]}, f3[2] = {rd_cur.f3[0], rd_cur.f3[1]};
     int last_cb = 0;
 
@@ -243,31 +270,32 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       bufsel = nb;
       last_cb = cb;
       const int nch0 = nsc_i * 4;
-      const char* lane_real = wrap ? lane0_nxt : lane0_cur + (long)nsc_i * scstride;
-      const bool n_ok = wrap ? st_nxt.ok : st_cur.ok;
       const int n_t = wrap ? st_nxt.t : st_cur.t;
       const char* anext = (wrap ? abase_nxt : abase_cur) + (long)nsc_i * ascstride;
       const unsigned ldsn = lds0 + (unsigned)((nb * BUFF + 1) * 4 + wave * 1024);
       float nf0[2], nf3[2];
       nf0[0] = wrap ? rd_nxt.f0[0] : f0[0]; nf0[1] = wrap ? rd_nxt.f0[1] : f0[1];
       nf3[0] = wrap ? rd_nxt.f3[0] : f3[0]; nf3[1] = wrap ? rd_nxt.f3[1] : f3[1];
-      // this item's row pointers (buffer cb) and the next item's (buffer nb; the next tile's geometry at a tile wrap)
-      const f32x2a* xa[2] = {reinterpret_cast<const f32x2a*>(xs + cb * BUFF + rd_cur.ba[0]),
-                             reinterpret_cast<const f32x2a*>(xs + cb * BUFF + rd_cur.ba[1])};
-      const f32x2a* xb[2] = {reinterpret_cast<const f32x2a*>(xs + cb * BUFF + rd_cur.bb[0]),
-                             reinterpret_cast<const f32x2a*>(xs + cb * BUFF + rd_cur.bb[1])};
-      const f32x2a* xan[2] = {reinterpret_cast<const f32x2a*>(xs + nb * BUFF + (wrap ? rd_nxt.ba[0] : rd_cur.ba[0])),
-                              reinterpret_cast<const f32x2a*>(xs + nb * BUFF + (wrap ? rd_nxt.ba[1] : rd_cur.ba[1]))};
-      const f32x2a* xbn[2] = {reinterpret_cast<const f32x2a*>(xs + nb * BUFF + (wrap ? rd_nxt.bb[0] : rd_cur.bb[0])),
-                              reinterpret_cast<const f32x2a*>(xs + nb * BUFF + (wrap ? rd_nxt.bb[1] : rd_cur.bb[1]))};
-      const char* stg_src = zero_ptr;
-#define W2R_STAGE_ADDR(PLN)                                                                                       \
+      // this item's row addresses (buffer cb) and the next item's (buffer nb; the next tile's geometry at a tile wrap)
+      const unsigned cbb = lds0 + (unsigned)(cb * BUFF) * 4u, nbb = lds0 + (unsigned)(nb * BUFF) * 4u;
+      const unsigned xa[2] = {cbb + (unsigned)rd_cur.ba[0] * 4u, cbb + (unsigned)rd_cur.ba[1] * 4u};
+      const unsigned xb[2] = {cbb + (unsigned)rd_cur.bb[0] * 4u, cbb + (unsigned)rd_cur.bb[1] * 4u};
+      const unsigned xan[2] = {nbb + (unsigned)(wrap ? rd_nxt.ba[0] : rd_cur.ba[0]) * 4u, nbb + (unsigned)(wrap ? rd_nxt.ba[1] : rd_cur.ba[1]) * 4u};
+      const unsigned xbn[2] = {nbb + (unsigned)(wrap ? rd_nxt.bb[0] : rd_cur.bb[0]) * 4u, nbb + (unsigned)(wrap ? rd_nxt.bb[1] : rd_cur.bb[1]) * 4u};
+      // plane pl = cc * 3 + dt of the next item into buffer nb: a valid plane comes through its scalar base + this lane's
+      // tile-constant byte offset under the tile's EXEC mask (no vector instruction at all: the fp32 MFMA shares the vector ALU),
+      // a plane outside the clip / past Cin from the zero word (every lane)
+      const char* pl_base = wrap ? plane0(st_nxt, 0) : plane0(st_cur, 0) + (long)nsc_i * scstride;
+      const unsigned n_voff = wrap ? st_nxt.voff : st_cur.voff;
+      const unsigned long long n_okm = wrap ? st_nxt.okm : st_cur.okm;
+#define W2R_STAGE_ADDR(PLN) {}
+#define W2R_STAGE(PLN)                                                                                            \
   {                                                                                                               \
     const int cc_ = (PLN) / 3, dt_ = (PLN) - 3 * cc_;                                                             \
     const bool pok_ = nch0 + cc_ < a.Cin && n_t + dt_ - 1 >= 0 && n_t + dt_ - 1 < a.T;                            \
-    stg_src = (pok_ && n_ok) ? lane_real + ((long)cc_ * THWb + (long)dt_ * HWb) : zero_ptr;                       \
+    if (pok_) conv_dma_piece16(pl_base + ((long)cc_ * THWb + (long)dt_ * HWb), n_voff, ldsn + (unsigned)((PLN) * PL * 4), n_okm); \
+    else conv_dma_piece16(zero_ptr, vzero, ldsn + (unsigned)((PLN) * PL * 4), ~0ull);                             \
   }
-#define W2R_STAGE(PLN) w2_dma16(stg_src, ldsn + (unsigned)((PLN) * PL * 4));
       // ---- wait counts (vector-memory ops return in order).  Per item this wave issues, in program order: step s < 3: four
       // DMA pieces (slots 1, 5, 9, 13), then the two U loads of ring slot s for the NEXT item (slots 14, 15); steps 3-5: the
       // two U loads only.  The U loads of slot s are used six steps later; issued after them by then: 5 x 2 U loads and
@@ -284,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[STEP][(K) >> 3][(K) & 3], VC[((K) >> 2) & 1][(K) & 3], acc[K], 0, 0, 0); \
     if ((K) == 0 && (STEP) < 5) W2R_LOAD_RAW(xa, xb, (STEP) + 1)                                                   \
     if ((K) == 0 && (STEP) == 5) W2R_LOAD_RAW(xan, xbn, 0)                                                         \
+    if ((K) == 4) W2R_WAIT_RAW();                                                                                  \
     if ((K) >= 4 && (K) < 8) W2R_VERT((((K) - 4) >> 1) & 1, (K) & 1)                                                     \
     if ((K) >= 8 && (K) < 12 && (STEP) < 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, f0, f3)                          \
     if ((K) >= 8 && (K) < 12 && (STEP) == 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, nf0, nf3)                       \
@@ -300,13 +329,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     W2R_SLOT(STEP, 8, VC, VN) W2R_SLOT(STEP, 9, VC, VN) W2R_SLOT(STEP, 10, VC, VN) W2R_SLOT(STEP, 11, VC, VN)      \
     W2R_SLOT(STEP, 12, VC, VN) W2R_SLOT(STEP, 13, VC, VN) W2R_SLOT(STEP, 14, VC, VN) W2R_SLOT(STEP, 15, VC, VN)    \
   }
+      stage_zero(wrap ? st_nxt : st_cur, nb);
       W2R_STEP(0, 18, vA, vB)
       W2R_STEP(1, 18, vB, vA)
       W2R_STEP(2, 18, vA, vB)
       W2R_STEP(3, 22, vB, vA)
       W2R_STEP(4, 22, vA, vB)
 #ifndef HPVG_ABL2_NOBAR
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: the zero words of stage_zero)
       if constexpr (TAIL) stage_tail(wrap ? st_nxt : st_cur, nsc_i, nb);
       asm volatile("s_barrier" ::: "memory");   // buffer nb is complete for every wave (and everybody is past the item before)
 #endif
@@ -453,4 +483,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #undef W2R_HORZ
 #undef W2R_VERT
 #undef W2R_LOAD_RAW
+#undef W2R_DSREAD
+#undef W2R_WAIT_RAW
 #undef W2R_WAIT_A
