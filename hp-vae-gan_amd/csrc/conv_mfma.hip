@@ -1300,17 +1300,15 @@ inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT)
   q.ok = true;
   return q;
 }
-// Taken by size where it was measured to win (tools/perf_wino.py, profiles/r02_perf_wino2d.txt): whole tiles, one
-// workgroup per CU and no stream-K want a few rounds of tiles - stage 9 (14.6 rounds at B = 2): 1.05 vs 1.31 ms for the
-// one-axis kernel + fix-up; stage 8 (5 rounds): 0.354 vs 0.458 (0.53 while its tiles were cut per quad row and filled 51
-// of their 64 quads).
-// Measured around the edge (stage 7, 826 tiles per sample pair): B = 2, 3.2 rounds -> 4 (81 % full): 0.320 vs 0.307 ms, loses;
-// B = 3, 4.8 -> 5 (97 %): x1.18; B = 4, 6.5 -> 7 (92 %): x1.11.  Rule: at least three rounds, filled to 88 % or more.
+// Taken by size where it was measured to win.  Whole tiles, one workgroup per CU and no stream-K want enough tiles to fill the
+// chip about twice.  Round 3, conv_wino2r_kernel against the one-axis kernel + fix-up (tools/perf_wino2.py,
+// profiles/r03_perf_wino2r_sizes.txt; rounds = tiles / 256): 0.94 rounds x1.00, 1.88 x1.11, 2.02 x1.08, 3.23 x1.10 (H * W = 2 mod
+// 4: the TAIL instance) / x1.17, 4.05 x1.18, 4.84 x1.22, 4.98 x1.37, 6.45 x1.17, 14.6 x1.33.  (Round 2, conv_wino2d_kernel:
+// 3.2 rounds lost 4 %, the rule was three rounds filled to 88 %.)  Rule: at least 1.8 rounds.
 inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
   if (g_wino2d == 2) return true;
-  const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
-  return rounds >= 3 && (double)q.ntl >= 0.88 * (double)(rounds * HPVG_NUM_CU);
+  return (long)q.ntl * 10 >= 18L * HPVG_NUM_CU;
 }
 // HPVG_WINO2R=0 keeps the first-generation kernel (every wave all 16 points of one block: conv_wino2d_kernel); default: the
 // points split over the waves by row (conv_wino2r_kernel: half the input-transform instructions and U loads per MFMA)

@@ -98,17 +98,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     q.tail = TAIL ? __builtin_amdgcn_readfirstlane(gt < ng ? gt : -1) : -1;   // uniform: keep it scalar
     return q;
   };
-  auto stage_tail = [&](const StageT& q, int sc, int bf) __attribute__((always_inline)) {
-    if (q.tail < 0) return;
-    if (tid == q.tail) {
-      const char* p0 = reinterpret_cast<const char*>(a.x) + (((long)q.b * a.Cin + (long)sc * 4) * a.T + (q.t - 1)) * HWb;
+  // (the tile is decoded again inside the rare branch: keeping b / t of two tiles alive through the K loop for it cost the TAIL
+  // instance its scalar registers - 24 v_readfirstlane and a scratch reload per item)
+  auto stage_tail = [&](int tile_, int tail_, int sc, int bf) __attribute__((always_inline)) {
+    if (tail_ < 0) return;
+    if (tid == tail_) {
+      int qb, qt, tp, yb;
+      decode(tile_, qb, qt, tp, yb);
+      const char* p0 = reinterpret_cast<const char*>(a.x) + (((long)qb * a.Cin + (long)sc * 4) * a.T + (qt - 1)) * HWb;
 #pragma unroll 1
       for (int pl = 0; pl < 12; ++pl) {
         const int cc = pl / 3, dt = pl - 3 * cc;
-        const int tt = q.t + dt - 1;
+        const int tt = qt + dt - 1;
         if (sc * 4 + cc < a.Cin && tt >= 0 && tt < a.T) {
           const float* src = reinterpret_cast<const float*>(p0 + ((long)cc * a.T + dt) * HWb) + (HWp - 2);
-          float* dst = xs + bf * BUFF + pl * PL + 1 + 4 * q.tail;
+          float* dst = xs + bf * BUFF + pl * PL + 1 + 4 * tail_;
           dst[0] = src[0];
           dst[1] = src[1];
         }
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     stage_zero(st_cur, 0);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if constexpr (TAIL) stage_tail(st_cur, 0, 0);
+  if constexpr (TAIL) stage_tail(tile, st_cur.tail, 0, 0);
   asm volatile("s_barrier" ::: "memory");
   {
     const unsigned xa0[2] = {lds0 + (unsigned)rd_cur.ba[0] * 4u, lds0 + (unsigned)rd_cur.ba[1] * 4u};
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       W2R_STEP(4, 22, vA, vB)
 #ifndef HPVG_ABL2_NOBAR
       asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: the zero words of stage_zero)
-      if constexpr (TAIL) stage_tail(wrap ? st_nxt : st_cur, nsc_i, nb);
+      if constexpr (TAIL) stage_tail(wrap ? ntile : tile, wrap ? st_nxt.tail : st_cur.tail, nsc_i, nb);
       asm volatile("s_barrier" ::: "memory");   // buffer nb is complete for every wave (and everybody is past the item before)
 #endif
       W2R_STEP(5, 22, vB, vA)
@@ -353,62 +357,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     // front of step 5, whose LDS reads are the next buffer's) nor the third buffer (the item before), and no DMA targets
     // either before the next item starts.  Region (sender v, destination block d != v) = 8 x 64 lanes x 16 bytes, six regions
     // per buffer; write k of a region holds (s0, s1) of the accumulator elements 2k and 2k + 1.
-    float own0[16], own1[16];
     {
       const int third = bufsel == 2 ? 0 : bufsel + 1;       // (bufsel = the next item's buffer)
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const int mt = blk & 1, qh = blk >> 1;
-        const int a0 = (mt * 2 + qh) * 4;
-        if (blk == wave) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            own0[e] = (acc[a0 + 0][e] + acc[a0 + 1][e]) + acc[a0 + 2][e];
-            own1[e] = (acc[a0 + 1][e] - acc[a0 + 2][e]) - acc[a0 + 3][e];
-          }
-        } else {
-          const int ridx = wave * 3 + (blk > wave ? blk - 1 : blk);
-          float* rg = xs + (ridx < 6 ? last_cb : third) * BUFF + (ridx < 6 ? ridx : ridx - 6) * 2048 + lane * 4;
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            f32x4 v;
-            v[0] = (acc[a0 + 0][2 * kk] + acc[a0 + 1][2 * kk]) + acc[a0 + 2][2 * kk];
-            v[1] = (acc[a0 + 1][2 * kk] - acc[a0 + 2][2 * kk]) - acc[a0 + 3][2 * kk];
-            v[2] = (acc[a0 + 0][2 * kk + 1] + acc[a0 + 1][2 * kk + 1]) + acc[a0 + 2][2 * kk + 1];
-            v[3] = (acc[a0 + 1][2 * kk + 1] - acc[a0 + 2][2 * kk + 1]) - acc[a0 + 3][2 * kk + 1];
-            *reinterpret_cast<f32x4*>(rg + kk * 256) = v;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // vertical half in row order (fixed: reproducible): Y[0][b] = S0 + S1 + S2, Y[1][b] = S1 - S2 - S3
-      float y0[16][2], y1[16][2];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float s0[16], s1[16];
-        if (v == wave) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { s0[e] = own0[e]; s1[e] = own1[e]; }
-        } else {
-          const int ridx = v * 3 + (wave > v ? wave - 1 : wave);
-          const float* rg = xs + (ridx < 6 ? last_cb : third) * BUFF + (ridx < 6 ? ridx : ridx - 6) * 2048 + lane * 4;
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(rg + kk * 256);
-            s0[2 * kk] = q4[0]; s1[2 * kk] = q4[1]; s0[2 * kk + 1] = q4[2]; s1[2 * kk + 1] = q4[3];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          if (v == 0) { y0[e][0] = s0[e]; y0[e][1] = s1[e]; }
-          if (v == 1) { y0[e][0] += s0[e]; y0[e][1] += s1[e]; y1[e][0] = s0[e]; y1[e][1] = s1[e]; }
-          if (v == 2) { y0[e][0] += s0[e]; y0[e][1] += s1[e]; y1[e][0] -= s0[e]; y1[e][1] -= s1[e]; }
-          if (v == 3) { y1[e][0] -= s0[e]; y1[e][1] -= s1[e]; }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the regions may be overwritten (the next item's DMA)
-
-      // ---- epilogue of the owned block (m-tile mw, quad half nw): bias, masks, 8-byte stores of the two output rows
+      // ---- what the epilogue of the owned block (m-tile mw, quad half nw) loads is issued first: its latency passes behind
+      // the exchange (one wave per SIMD: nothing else would hide it)
       const int mt = c_yb * 2 + mw;
       const bool mt_ok = mt * 32 < a.Cout;
       const long HW = (long)HWp;
@@ -431,17 +383,72 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
         mwd[2] = a.mask_bits[r1ok ? (w0 + (long)W * a.mbreal < wmax ? w0 + (long)W * a.mbreal : wmax) : 0];
         mwd[3] = a.mask_bits[r1ok ? (w0 + (long)(W + 1) * a.mbreal < wmax ? w0 + (long)(W + 1) * a.mbreal : wmax) : 0];
       }
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const int bmt = blk & 1, bqh = blk >> 1;
+        const int a0 = (bmt * 2 + bqh) * 4;
+        if (blk != wave) {
+          const int ridx = wave * 3 + (blk > wave ? blk - 1 : blk);
+          float* rg = xs + (ridx < 6 ? last_cb : third) * BUFF + (ridx < 6 ? ridx : ridx - 6) * 2048 + lane * 4;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            f32x4 v;
+            v[0] = (acc[a0 + 0][2 * kk] + acc[a0 + 1][2 * kk]) + acc[a0 + 2][2 * kk];
+            v[1] = (acc[a0 + 1][2 * kk] - acc[a0 + 2][2 * kk]) - acc[a0 + 3][2 * kk];
+            v[2] = (acc[a0 + 0][2 * kk + 1] + acc[a0 + 1][2 * kk + 1]) + acc[a0 + 2][2 * kk + 1];
+            v[3] = (acc[a0 + 1][2 * kk + 1] - acc[a0 + 2][2 * kk + 1]) - acc[a0 + 3][2 * kk + 1];
+            *reinterpret_cast<f32x4*>(rg + kk * 256) = v;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // vertical half in row order (fixed: reproducible), started from the bias: Y[0][b] = S0 + S1 + S2, Y[1][b] = S1 - S2 - S3.
+      // The wave's own row comes straight from its accumulators (block index = wave = row index on that branch).
+      float y0[16][2], y1[16][2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { y0[e][0] = bias_r[e]; y0[e][1] = bias_r[e]; y1[e][0] = bias_r[e]; y1[e][1] = bias_r[e]; }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (v == wave) {
+          const int a0 = ((v & 1) * 2 + (v >> 1)) * 4;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float s0 = (acc[a0 + 0][e] + acc[a0 + 1][e]) + acc[a0 + 2][e];
+            const float s1 = (acc[a0 + 1][e] - acc[a0 + 2][e]) - acc[a0 + 3][e];
+            if (v < 3) { y0[e][0] += s0; y0[e][1] += s1; }
+            if (v == 1) { y1[e][0] += s0; y1[e][1] += s1; }
+            if (v >= 2) { y1[e][0] -= s0; y1[e][1] -= s1; }
+          }
+        } else {
+          const int ridx = v * 3 + (wave > v ? wave - 1 : wave);
+          const float* rg = xs + (ridx < 6 ? last_cb : third) * BUFF + (ridx < 6 ? ridx : ridx - 6) * 2048 + lane * 4;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(rg + kk * 256);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const int e = 2 * kk + h2;
+              const float s0 = q4[2 * h2], s1 = q4[2 * h2 + 1];
+              if (v < 3) { y0[e][0] += s0; y0[e][1] += s1; }
+              if (v == 1) { y1[e][0] += s0; y1[e][1] += s1; }
+              if (v >= 2) { y1[e][0] -= s0; y1[e][1] -= s1; }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the regions may be overwritten (the next item's DMA)
+
+      // ---- epilogue of the owned block: masks, 8-byte stores of the two output rows
       const bool lrelu = a.out_lrelu != 0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int shb = (e & 3) + 8 * (e >> 2) + 4 * half;
         const int co = mt * 32 + shb;
-        const float bv = bias_r[e];
         float yv[4];
-        yv[0] = y0[e][0] + bv;
-        yv[1] = y0[e][1] + bv;
-        yv[2] = y1[e][0] + bv;
-        yv[3] = y1[e][1] + bv;
+        yv[0] = y0[e][0];
+        yv[1] = y0[e][1];
+        yv[2] = y1[e][0];
+        yv[3] = y1[e][1];
         if constexpr (VAR == VAR_BITS) {
 #pragma unroll
           for (int p = 0; p < 4; ++p) wrd[p] |= (yv[p] > 0.f ? 1u : 0u) << shb;
