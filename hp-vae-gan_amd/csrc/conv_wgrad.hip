@@ -1240,16 +1240,16 @@ inline size_t wgradw_slab_bytes(const WPlan& p, int KT) { return (size_t)p.S * K
 // (+ the per-slot bias partials [S][nob][64] behind the slabs)
 inline size_t wgradw_ws_bytes(const WPlan& p, int KT) { return 256 + wgradw_slab_bytes(p, KT) + (size_t)p.S * p.nob * 64 * sizeof(float); }
 // HPVG_WGRAD_WINO (read once; hpvg_conv_bwd_weight_wino_config changes it at run time): 0 = never the Winograd weight
-// gradient, 2 = every wide layer, 1 / unset = by size (see wgradw_wanted)
+// gradient (the direct kernels: conv_wgrad_kernel / conv_wgrad3_kernel), anything else = EVERY wide layer (Cin > 4 and Cout > 4).
+// There is no size rule at this level: the one-axis kernel with the slot-grouped reduce wins at every pyramid stage, 2-D and
+// 3-D (profiles/r02_perf_wgrad_wino.txt); what IS chosen by size is which Winograd kernel runs (wgradw2_wanted below).
 int g_wgradw_mode = -1;
 inline bool wgradw_wanted(const WPlan& p, int B, int Cin, int Cout, int T, int H, int W, int KT) {
   if (g_wgradw_mode < 0) {
     const char* e = getenv("HPVG_WGRAD_WINO");
     g_wgradw_mode = e ? atoi(e) : 1;
   }
-  if (g_wgradw_mode == 0 || p.Th == 0 || Cin <= 4 || Cout <= 4) return false;
-  if (g_wgradw_mode == 2) return true;
-  return true;
+  return g_wgradw_mode != 0 && p.Th != 0 && Cin > 4 && Cout > 4;
 }
 
 // Tile plan of conv_wgradw2_kernel (Winograd over H and W): the 16-byte staging form with an EVEN tile height (rows of quads)
@@ -1771,7 +1771,8 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
   return hpvg_launch_status();
 }
 
-// Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never, 1 = by size, 2 = every wide layer, 3 = every
+// Run-time switch of the Winograd weight gradient (tests and A/B tools): 0 = never (the direct kernels), 1 = the default (every
+// wide layer on a Winograd kernel; the two-axis one where wgradw2_wanted's size rule picks it), 2 = every wide layer, 3 = every
 // wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
 // HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis
 // kernel (conv_wgradw2_kernel) wherever it can run (W % 4 == 0); 6 = the one-axis kernel only; a negative mode only queries.

@@ -109,6 +109,13 @@ def pair_swap(peer, group=None):
     return swap
 
 
+def _next_iteration(be, device):
+    """noise-stream bookkeeping of a backend, once per train iteration (the CPU test backends have none)"""
+    f = getattr(be, "next_iteration", None)
+    if f is not None:
+        f(device)
+
+
 class HipBackend:
     """Losses / optimisers of the product path (gfx950 kernels)."""
 
@@ -130,6 +137,16 @@ class HipBackend:
     def grad_penalty(self, netD, real, fake, lam, alpha):
         from .modules.utils import calc_gradient_penalty
         return calc_gradient_penalty(netD, real, fake, lam, real.device, alpha=alpha)
+
+    def next_iteration(self, device):
+        """Start the library noise stream of the next train iteration (ops.rng_next_iteration, as StageTrainer.step does):
+        the stream is keyed (torch seed, iteration counter on the device, call index inside the iteration), so the call index
+        restarts every iteration instead of growing for the whole run.  Every rank seeds alike and draws the FULL-batch noise
+        at the same (iteration, call) - identical tensors on all ranks, which the schedules then slice per rank; a draw that is
+        meant to differ between ranks must be sliced from such a full-batch draw (nothing folds the rank into the key)."""
+        from . import ops
+        if torch.device(device).type == "cuda":
+            ops.rng_next_iteration(device)
 
     def optimizers(self, netG, netD, g_groups, lr_d, beta1):
         from . import optim as hp_optim
@@ -316,6 +333,7 @@ class DistStageTrainer:
     # ---- one iteration
     def step(self, real, real_zero, noise_init=None, alpha=None):
         opt = self.opt
+        _next_iteration(self.be, real.device)
         if not self.is_gan:
             return self._vae_step(real, real_zero)
         if self.iteration == 0:

@@ -20,7 +20,7 @@ Backend-agnostic like multigpu.DistStageTrainer: HipPipeBackend (gfx950 kernels)
 import torch
 import torch.distributed as dist
 
-from .multigpu import all_reduce, broadcast, recv, send
+from .multigpu import _next_iteration, all_reduce, broadcast, recv, send
 
 
 def level_costs(shapes, batch, has_d):
@@ -71,7 +71,7 @@ class HipPipeBackend:
         from .multigpu import HipBackend
         self.opt = opt
         self.base = HipBackend(opt)
-        for name in ("mse", "kl", "wgan_mean", "grad_penalty", "noise"):
+        for name in ("mse", "kl", "wgan_mean", "grad_penalty", "noise", "next_iteration"):
             setattr(self, name, getattr(self.base, name))
 
     def g_head(self, netG, video, amps, noise_init, mode, stop):
@@ -210,6 +210,7 @@ class LevelPipelineTrainer:
 
     def step(self, real, real_zero, noise_init=None, alpha=None):
         opt, be = self.opt, self.be
+        _next_iteration(be, real.device)
         if self.iteration == 0:
             self.calibrate_noise_amp(real, real_zero)
         self.iteration += 1
@@ -391,6 +392,7 @@ class BaselinePipelineTrainer:
 
     def step(self, real, noise_init=None, alphas=None):
         opt, be = self.opt, self.be
+        _next_iteration(be, real.device)
         if self.iteration == 0:
             if opt.scale_idx == 0:
                 opt.noise_amp = 1

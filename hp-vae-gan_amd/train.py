@@ -71,26 +71,62 @@ def _capture_iteration(trainer, run, nets):
     it = trainer.iteration
     graph = torch.cuda.CUDAGraph(keep_graph=True)   # keep the hipGraph_t: its nodes are inspected below
     # host-side state that python advances while it records the iteration: BatchNorm forward counts (replays must add
-    # the same amounts, the capture itself must not count)
+    # the same amounts, the capture itself must not count), the optimizers' host step counts, the noise stream's call index
     bns = [m for net in nets if net is not None for m in net.modules() if hasattr(m, 'pending_batches')]
     before = [m.pending_batches for m in bns]
+    host = _host_state(trainer)
     ops.weights_changed()  # packed weights made outside the capture must not be baked into it, nor its buffers reused after
-    with torch.cuda.graph(graph):
-        trainer._g_out = run()
-    ops.weights_changed()
-    trainer.graph_nodes = graph_node_census(graph)
-    bad = {k: v for k, v in trainer.graph_nodes.items() if k not in ("kernel", "empty", "event_record", "wait_event") and v}
-    if bad:
-        # memcpy / memset nodes are not reliably ordered against kernel nodes on this runtime (replays
-        # trained NaNs); whatever put them there (a torch fill / slice-backward / pad lowering) must become a kernel
-        trainer._graph = None
-        raise RuntimeError("the captured iteration holds non-kernel graph nodes %s (of %s): refusing to replay it" % (bad, trainer.graph_nodes))
-    graph.instantiate()
-    trainer._graph = graph
-    trainer._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
-    for m, b in zip(bns, before):
-        m.pending_batches = b
-    trainer.iteration = it
+    ok = False
+    try:
+        with torch.cuda.graph(graph):
+            trainer._g_out = run()
+        ops.weights_changed()
+        trainer.graph_nodes = graph_node_census(graph)
+        bad = {k: v for k, v in trainer.graph_nodes.items() if k not in ("kernel", "empty", "event_record", "wait_event") and v}
+        if bad:
+            # memcpy / memset nodes are not reliably ordered against kernel nodes on this runtime (replays
+            # trained NaNs); whatever put them there (a torch fill / slice-backward / pad lowering) must become a kernel
+            raise GraphCaptureRefused("the captured iteration holds non-kernel graph nodes %s (of %s): refusing to replay it"
+                                      % (bad, trainer.graph_nodes))
+        graph.instantiate()
+        trainer._graph = graph
+        trainer._graph_bn = [(m, m.pending_batches - b) for m, b in zip(bns, before) if m.pending_batches != b]
+        ok = True
+    finally:
+        # the capture recorded launches, it did not execute an iteration: whatever the host advanced while recording goes
+        # back - also when the capture is refused or fails, so that a caller who catches the error continues eagerly from a
+        # consistent state
+        for m, b in zip(bns, before):
+            m.pending_batches = b
+        trainer.iteration = it
+        if not ok:
+            trainer._graph = None
+            trainer._g_out = None
+            _restore_host_state(trainer, host)
+
+
+class GraphCaptureRefused(RuntimeError):
+    """the captured iteration cannot be replayed safely (non-kernel graph nodes); the trainer is left in its eager state"""
+
+
+def _host_state(trainer):
+    """host-side counters a recorded (not executed) iteration advances: the optimizers' step counts and the noise stream's
+    call index of the trainer's device"""
+    st = {"opt": [(o, o.t) for o in (getattr(trainer, n, None) for n in ("optimizerG", "optimizerD")) if o is not None and hasattr(o, "t")]}
+    dev = getattr(getattr(trainer, "opt", None), "device", None)
+    try:
+        rs = ops._rng(torch.device(dev)) if dev is not None and torch.device(dev).type == "cuda" else None
+    except Exception:   # (no device: the CPU unit test of this path)
+        rs = None
+    st["rng"] = (rs, rs.call) if rs is not None else None
+    return st
+
+
+def _restore_host_state(trainer, st):
+    for o, t in st["opt"]:
+        o.t = t
+    if st["rng"] is not None:
+        st["rng"][0].call = st["rng"][1]
 
 
 def _replay_iteration(trainer):
@@ -262,7 +298,14 @@ def train(opt, netG, data, netD=None, niter=None):
         # eager).  Capturing runs one more real iteration on this batch first (side-stream warm-up), which counts.
         if (trainer.iteration == 2 and n - trainer.iteration >= 2 and getattr(opt, 'hip_graph', True)
                 and getattr(trainer, '_graph', None) is None and real.is_cuda):
-            trainer.enable_graph(real, real_zero)
+            try:
+                trainer.enable_graph(real, real_zero)
+            except GraphCaptureRefused as e:
+                # a torch lowering change put a memcpy / memset node into the iteration: say so and train on eagerly (the
+                # trainer's host state was put back by _capture_iteration)
+                print("hp-vae-gan_amd: hipGraph replay off for stage %d (%s; node census %s)"
+                      % (opt.scale_idx, e, getattr(trainer, "graph_nodes", None)))
+                opt.hip_graph = False
     return trainer
 
 

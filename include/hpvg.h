@@ -102,8 +102,10 @@ int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int
 int hpvg_conv_bwd_weight_kernel_kind(int B, int Cin, int Cout, int T, int H, int W, int KT);
 /* Wide layers (Cin > 4 and Cout > 4) have a Winograd weight-gradient kernel behind the same entry point (the transpose of
  * the forward F(2,3) along W: four products per pair of output columns and (dt, dh) instead of six, summed over all
- * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never, 1 = by size, 2 = every wide
- * layer, 3 = every wide layer without the 16-byte staging form (widths that are multiples of 4 otherwise get it), 4 = every
+ * positions before the output transform: 2/3 of the matrix-core work, fp32).  mode 0 = never (the direct kernels), 1 = the
+ * default: every wide layer on a Winograd kernel - the one-axis kernel wins at every size - and the two-axis kernel (mode 5)
+ * where its size rule picks it, 2 = every wide layer on the one-axis kernel,
+ * 3 = every wide layer without the 16-byte staging form (widths that are multiples of 4 otherwise get it), 4 = every
  * wide layer with the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis kernel (the transpose
  * of F(2x2,3x3) over H and W: 16 products per 2 x 2 output positions and dt instead of 36, 4/9 of the direct matrix-core work)
  * wherever it can run (W % 4 == 0; by default it takes the launches whose workgroups walk enough tiles), 6 = every wide layer,

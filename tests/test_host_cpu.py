@@ -311,3 +311,69 @@ def test_narrow_conv_plan_keeps_every_load_inside_the_image():
                 assert nxt == W
     assert lib.hpvg_conv_narrow_plan(2, 5, 3, 5, 9, 16, 3, out) != 0    # odd Cin: first-generation kernel
     assert lib.hpvg_conv_narrow_plan(2, 64, 3, 5, 9, 3, 3, out) != 0    # narrower than one 16-byte group
+
+
+def test_graph_capture_refusal_restores_host_state(monkeypatch):
+    """_capture_iteration on a stubbed device: when the captured graph holds a memset node the capture is refused
+    with GraphCaptureRefused and everything the host advanced while RECORDING the iteration - the trainer's iteration count,
+    BatchNorm's pending forward counts, the optimizers' step counts, the noise stream's call index - is back where it was, so
+    a caller that catches the error trains on eagerly from a consistent state; the accepted capture keeps its replay deltas."""
+    import contextlib
+    import types
+    import torch
+    from hp_vae_gan_amd import train as T
+
+    class _Stream:
+        def wait_stream(self, other):
+            pass
+
+    class _Graph:
+        def __init__(self, keep_graph=True):
+            pass
+
+        def instantiate(self):
+            self.ok = True
+
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: _Stream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _Graph)
+    monkeypatch.setattr(torch.cuda, "graph", lambda g: contextlib.nullcontext())
+    monkeypatch.setattr(T.ops, "pin_workspaces", lambda: None)
+    census = {}
+    monkeypatch.setattr(T, "graph_node_census", lambda g: dict(census))
+
+    class BN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pending_batches = 7
+
+    net = torch.nn.Sequential(BN(), BN())
+    opt_g, opt_d = types.SimpleNamespace(t=11), types.SimpleNamespace(t=5)
+    rng = types.SimpleNamespace(call=3)
+    trainer = types.SimpleNamespace(iteration=4, optimizerG=opt_g, optimizerD=opt_d, opt=types.SimpleNamespace(device="cpu"), _graph=None)
+    monkeypatch.setattr(T, "_host_state", lambda tr: {"opt": [(opt_g, opt_g.t), (opt_d, opt_d.t)], "rng": (rng, rng.call)})
+
+    def run():   # what recording an iteration does to the host
+        trainer.iteration += 1
+        for m in net:
+            m.pending_batches += 2
+        opt_g.t += 1
+        opt_d.t += 1
+        rng.call += 9
+        return {"loss": 1.0}
+
+    census.update(kernel=40, memset=1)
+    with pytest.raises(T.GraphCaptureRefused):
+        T._capture_iteration(trainer, run, (net, None))
+    # (the warm-up run on the side stream is a REAL iteration and counts: one run's worth; the recorded one is undone)
+    assert trainer.iteration == 5 and [m.pending_batches for m in net] == [9, 9]
+    assert (opt_g.t, opt_d.t, rng.call) == (12, 6, 12)
+    assert trainer._graph is None and trainer._g_out is None
+
+    census.clear()
+    census.update(kernel=40)
+    T._capture_iteration(trainer, run, (net, None))
+    assert trainer.iteration == 6 and [m.pending_batches for m in net] == [11, 11]          # warm-up counted, recording undone
+    assert trainer._graph is not None and trainer._g_out == {"loss": 1.0}
+    assert [(m.pending_batches, d) for m, d in trainer._graph_bn] == [(11, 2), (11, 2)]    # what every replay adds
