@@ -1253,16 +1253,17 @@ inline bool wgradw_wanted(const WPlan& p, int B, int Cin, int Cout, int T, int H
 }
 
 // Tile plan of conv_wgradw2_kernel (Winograd over H and W): the 16-byte staging form with an EVEN tile height (rows of quads)
-// and its K loop's cost (16 MFMAs per two quads = 8 positions).  W must be a multiple of 4.
+// and its K loop's cost (16 MFMAs per two quads = 8 positions).  W must be even (W = 2 mod 4: the kernel patches the one group
+// per row that straddles the right border).
 WPlan plan_wgradw2_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   WPlan best{};
-  if (W % 4 != 0) return best;
+  if (W % 2 != 0) return best;
   double best_cost = 1e300;
   const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
   int prev_tw = 0;
   // development: HPVG_WG2_FORCE="Th,Tw" restricts the search to that tile
   static const int force = [] { const char* e = getenv("HPVG_WG2_FORCE"); int a = 0, b = 0; return e && sscanf(e, "%d,%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
-  for (int ntw = W / 4; ntw >= 1; --ntw) {
+  for (int ntw = hpvg_cdiv(W, 4); ntw >= 1; --ntw) {
     const int Tw = 4 * hpvg_cdiv(hpvg_cdiv(W, ntw), 4);
     if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;
     prev_tw = Tw;
@@ -1576,23 +1577,31 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
       hipStream_t s = (hipStream_t)stream;
       const dim3 grid((KT == 3 ? 2 * p2.S0 + p2.S : p2.S) * p2.nob * p2.ncb);
       const int gjd = hpvg_cdiv(p2.Th * (p2.Tw / 4), 64), gjx = hpvg_cdiv((p2.Th + 2) * (p2.Tw / 4 + 2), 64);
-#define HPVG_W2_LAUNCH(K, D, X, TWC)                                                                                   \
+#define HPVG_W2_LAUNCH(K, D, X, TWC, ST)                                                                               \
   {                                                                                                                    \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw2_kernel<K, D, X, TWC>),                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradw2_kernel<K, D, X, TWC, ST>),                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                   \
         (void)hipGetLastError();                                                                                       \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X, TWC>), grid, dim3(256), p2.lds, s, a);                            \
+    hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X, TWC, ST>), grid, dim3(256), p2.lds, s, a);                        \
   }
-      // (the 16-column band - the tile of the large launches - has its row strides as immediates: one address register per operand)
+      // (the 16-column band - the tile of the large launches - has its row strides as immediates: one address register per
+      // operand; W = 2 (mod 4) runs the instance that patches the straddling groups)
 #define HPVG_W2_PICK(K)                                                                                                \
-  if (gjd == 1 && gjx == 1 && p2.Tw == 16) HPVG_W2_LAUNCH(K, 1, 1, 16)                                                 \
-  else if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1, 0)                                                            \
-  else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2, 0)                                                                        \
-  else HPVG_W2_LAUNCH(K, 2, 2, 0)
+  if (W & 2) {                                                                                                         \
+    if (gjd == 1 && gjx == 1 && p2.Tw == 16) HPVG_W2_LAUNCH(K, 1, 1, 16, true)                                         \
+    else if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1, 0, true)                                                    \
+    else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2, 0, true)                                                                \
+    else HPVG_W2_LAUNCH(K, 2, 2, 0, true)                                                                              \
+  } else {                                                                                                             \
+    if (gjd == 1 && gjx == 1 && p2.Tw == 16) HPVG_W2_LAUNCH(K, 1, 1, 16, false)                                        \
+    else if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1, 0, false)                                                   \
+    else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2, 0, false)                                                               \
+    else HPVG_W2_LAUNCH(K, 2, 2, 0, false)                                                                             \
+  }
       if (KT == 3) {
         HPVG_W2_PICK(3)
       } else {
@@ -1775,7 +1784,7 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
 // wide layer on a Winograd kernel; the two-axis one where wgradw2_wanted's size rule picks it), 2 = every wide layer, 3 = every
 // wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
 // HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis
-// kernel (conv_wgradw2_kernel) wherever it can run (W % 4 == 0); 6 = the one-axis kernel only; a negative mode only queries.
+// kernel (conv_wgradw2_kernel) wherever it can run (even W); 6 = the one-axis kernel only; a negative mode only queries.
 // Returns the mode in force.
 int hpvg_conv_bwd_weight_wino_config(int mode) {
   (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the defaults

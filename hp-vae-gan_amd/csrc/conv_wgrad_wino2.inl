@@ -22,7 +22,11 @@
 // scheme of conv_wino2d_kernel): slot 0 the LDS reads of the next step's operands, 3 the vertical pass of its dY quad, 4-7 the
 // vertical pass of its input patch, 8-11 the horizontal pass, 12-15 the horizontal pass of the dY quad, 1 / 5 / 9 (/ 13) an
 // LDS-DMA piece of the next tile.
-// Tiles: Th x Tw output positions, Th even, Tw and the band origins multiples of 4 (W a multiple of 4): the 16-byte staging form
+// Widths: W even.  W = 2 (mod 4): the one 16-byte group per row that straddles the right image border (columns W - 2 .. W + 1) is
+// zero-sourced like every group outside, and the wave that stages the channel patches its two valid floats in with an ordinary
+// in-bounds 8-byte load + LDS write after the tile's pieces have landed (border-band tiles only: ~4 loads and 8 LDS writes per
+// wave and tile, behind the same wait the barrier needs anyway) - nothing is ever read past a row or a tensor.
+// Tiles: Th x Tw output positions, Th even, Tw and the band origins multiples of 4: the 16-byte staging form
 // of conv_wgradw_kernel - a dY row is Tw floats, an X row Tw + 8 floats from column w0 - 4 one float into its channel row, so
 // that the patch pairs (first column w0 + 2C - 1) are 8-byte aligned; groups outside the image are zero-sourced, rows past H
 // too (odd H: the second row of the last quad row holds zeros on both sides).
@@ -30,7 +34,9 @@
 // a.order: the walk over the tiles.  0: time-major (tile = ((b * nth + th) * ntw + tw) * T + t: the slots of an XCD hold one
 // spatial tile at neighbouring t); 1: plane-major (tile = ((b * T + t) * nth + th) * ntw + tw: the slots of an XCD hold
 // neighbouring tiles of one plane, which share halo columns / rows and the other halves of their 128-byte lines in that XCD's L2)
-template <int KT, int NJD, int NJX, int TWC>
+// STRAD: W = 2 (mod 4) - a separate instance, so that the usual one carries none of the patch code (present but never executed it
+// cost the stage-9 launch 3 %: registers)
+template <int KT, int NJD, int NJX, int TWC, bool STRAD>
 __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NW = 4, NT = 256, NCH = 16, LW = 64, PW = 256;
@@ -109,6 +115,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       b = r / a.T;
     }
   };
+  // the staged tile's straddling groups (W = 2 mod 4; -1: none): float offset of the group inside a dY row / an X row, and what
+  // the patch needs to find the rows again
+  int pt_sd = -1, pt_sx = -1, pt_h0 = 0;
+  bool pt_tok = false;
+  const float* pt_dyb = nullptr;
+  const float* pt_xb = nullptr;
   auto setup = [&](int tile) {
     int b, t, th_i, tw_i;
     decode(tile, b, t, th_i, tw_i);
@@ -117,12 +129,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     const int h0 = th_i * a.Th, w0 = tw_i * Tw;
     const float* dyb = a.dy + (((long)b * a.Cout + ob * 64 + wave) * a.T + t) * HW;
     const float* xb = a.x + (((long)b * a.Cin + cb * 64 + wave) * a.T + (tok ? tt : 0)) * HW;
+    if constexpr (STRAD) {
+      const int sd = a.W - 2 - w0, sx = a.W - 2 - (w0 - 4);
+      pt_sd = (sd >= 0 && sd < Tw) ? sd : -1;
+      pt_sx = (sx >= 0 && sx < Tw + 8) ? sx : -1;
+      pt_h0 = h0; pt_tok = tok; pt_dyb = dyb; pt_xb = xb;
+    }
 #pragma unroll
     for (int j = 0; j < NJD; ++j) {
       const int p = j * LW + lane;
       const int hh = p / gpr, ww = 4 * (p - hh * gpr);
       const int gh = h0 + hh, gw = w0 + ww;
-      const bool ok = hh < a.Th && gh < a.H && gw < a.W;
+      const bool ok = hh < a.Th && gh < a.H && gw + (STRAD ? 3 : 0) < a.W;   // (a group is loaded when it lies wholly inside the row)
       dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
       dstr[j] = ok ? cbytes : 0u;
     }
@@ -131,9 +149,33 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       const int p = j * LW + lane;
       const int hh = p / gprx, ww = 4 * (p - hh * gprx) - 3;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
-      const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw + (STRAD ? 3 : 0) < a.W;
       xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
       xstr[j] = ok ? cbytes : 0u;
+    }
+  };
+  // W = 2 (mod 4): the two valid floats of the straddling group of every row of the tile staged into `buf`, for the 16 channels
+  // this wave stages - after the tile's pieces were issued (the load's wait also covers them: vector-memory results return in
+  // order, so the zero words the 16-byte pieces wrote there have landed before these LDS writes)
+  auto patch_straddle = [&](float* buf) {
+    if (pt_sd < 0 && pt_sx < 0) return;
+    const int nrow = 2 * a.Th + 2;                 // per channel: Th dY rows, Th + 2 X rows
+    for (int id0 = 0; id0 < NCH * nrow; id0 += 64) {
+      const int id = id0 + lane;
+      const int k = id / nrow, rr = id - k * nrow;
+      const bool isd = rr < a.Th;
+      const int hh = isd ? rr : rr - a.Th;
+      const int ch = NW * k + wave;
+      const int gh = isd ? pt_h0 + hh : pt_h0 + hh - 1;
+      const bool live = id < NCH * nrow && gh >= 0 && gh < a.H &&
+                        (isd ? (pt_sd >= 0 && ch < no) : (pt_sx >= 0 && ch < nc && pt_tok));
+      if (live) {
+        const float* src = (isd ? pt_dyb : pt_xb) + (long)k * NW * cstride + (long)gh * a.W + (a.W - 2);
+        const wf32x2a v = *reinterpret_cast<const wf32x2a*>(src);
+        float* dst = isd ? buf + ch * DS + hh * Tw + pt_sd : buf + 64 * DS + ch * XS + 1 + hh * RS + pt_sx;
+        dst[0] = v[0];
+        dst[1] = v[1];
+      }
     }
   };
   auto tile_has_work = [&](int tile) __attribute__((always_inline)) -> bool {
@@ -185,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     dma_begin(lds);
     cnext = 0;
     while (cnext < NCH) dma_channel();
+    if constexpr (STRAD) patch_straddle(lds);
   }
   __syncthreads();  // (waits for the DMA: pending LDS-DMA counts on vmcnt)
 
@@ -348,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       bsum = 0.f;
     }
     while (cnext < NCH) dma_channel();  // whatever did not fit into the K loop (short loops, idle waves, skipped tiles)
+    if constexpr (STRAD) { if (have_next) patch_straddle(lds + (cur ^ 1) * BUF); }
     __syncthreads();  // next buffer complete (the barrier's fence waits for the pending LDS-DMA), current one free
     cur ^= 1;
   }

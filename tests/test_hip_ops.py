@@ -234,6 +234,9 @@ def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, win
     # (mode 5: the two-axis kernel on every W % 4 == 0 shape above - odd H, H = 1, tiles padded to an even number of K steps,
     # several pieces per row, ragged bands and channel blocks - and on these: one tile exactly, a single row, 2-D one quad row)
     (1, 64, 64, (2, 6, 16)), (2, 64, 64, (3, 1, 4)), (1, 64, 64, (2, 12)), (2, 70, 40, (2, 13, 24)),
+    # W = 2 (mod 4) (also (3, 5, 6), (3, 30, 50), (2, 9, 130), (9, 10) above): the group that straddles the right border is
+    # patched - a last band of two columns (162 = 10 x 16 + 2: the band before it has the straddler in its halo), W = 2, 2-D
+    (1, 64, 64, (2, 13, 162)), (2, 64, 64, (2, 7, 2)), (1, 72, 64, (3, 4, 18)), (2, 64, 64, (21, 38)),
 ])
 def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(ops, B, Cin, Cout, sp):
     """conv_wgradw_kernel (transposed F(2,3) along W, output transform in its reduce kernel; forced for every wide layer)
@@ -255,9 +258,9 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
         bbase = _rand(Cout, seed=35).to(DEV)
         for mode in (2, 3, 4, 5, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
-            if Cin > 4 and Cout > 4:   # mode 5 = the two-axis kernel wherever W is a multiple of 4, the one-axis kernel elsewhere
+            if Cin > 4 and Cout > 4:   # mode 5 = the two-axis kernel wherever W is even, the one-axis kernel elsewhere
                 kind = lib.hpvg_conv_bwd_weight_kernel_kind(B, Cin, Cout, sp[0] if nd == 3 else 1, sp[-2], sp[-1], 3 if nd == 3 else 1)
-                assert kind == ((3 if sp[-1] % 4 == 0 else 2) if mode == 5 else (2 if mode >= 2 else kind)) and (mode or kind in (0, 1))
+                assert kind == ((3 if sp[-1] % 2 == 0 else 2) if mode == 5 else (2 if mode >= 2 else kind)) and (mode or kind in (0, 1))
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
             assert ops.conv_bwd_weight_raw(gyd, xd, w.shape, into=acc) is None

@@ -17,7 +17,7 @@ def test_wide_train_step_matches_reference(fname):
 
 # hpvg_conv_wino_config modes: 1 = by size (the default), 5 = the two-axis Winograd kernel wherever it can run (even W),
 # 3 / 4 = the one-axis kernel with the rows-as-in-memory / halo'd-band staging form, 0 = the direct kernel;
-# hpvg_conv_bwd_weight_wino_config modes: 1 = default, 5 = the two-axis Winograd kernel wherever W % 4 == 0, 2 = the one-axis kernel
+# hpvg_conv_bwd_weight_wino_config modes: 1 = default, 5 = the two-axis Winograd kernel wherever W is even, 2 = the one-axis kernel
 # on every wide layer, 4 = its 16-byte form on four waves, 3 = its 4-byte form only, 0 = the direct weight-gradient kernels
 CONV_MODES = [1, 5, 3, 4, 0]
 WGRAD_MODES = [1, 5, 2, 4, 3, 0]
@@ -67,7 +67,7 @@ def test_forced_modes_select_the_kernels_they_name():
                     lib.hpvg_conv_bwd_weight_wino_config(m)
                     assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) == 2
                 lib.hpvg_conv_bwd_weight_wino_config(5)
-                assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) == (3 if W % 4 == 0 else 2)
+                assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) == 3      # (every even width: 48, 72 and 78 = 2 mod 4)
                 lib.hpvg_conv_bwd_weight_wino_config(0)
                 assert lib.hpvg_conv_bwd_weight_kernel_kind(*geo) in (0, 1)
     finally:
