@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
       const int gw = w0 + ww;
       const bool ok = q < a.L && ww < a.Tw && gh < a.H && gw < a.W;
       const long sp = (long)t * HW + (long)gh * a.W + gw;
-      const long wi = ((long)b * a.T * HW + sp) * a.mbtot + mb0;   // first mask word of this position
+      const long wi = ((long)b * a.mbtot + mb0) * a.T * HW + sp;   // mask word of this position, m-tile mb0; m-tile + m: + m * T*H*W
       if constexpr (VAR == VAR_BITS) {
         // (every lane takes part in the cross-half exchange below, so no early exit before it)
 #pragma unroll
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
             word |= (val > 0.f ? 1u : 0u) << ((e & 3) + 8 * (e >> 2) + 4 * half);
           }
           word |= (unsigned)__shfl_xor((int)word, 32, 64);      // the two half-waves hold complementary channels of one position
-          if (ok && half == 0 && (mb0 + m) * 32 < a.Cout) a.bits_out[wi + m] = word;
+          if (ok && half == 0 && (mb0 + m) * 32 < a.Cout) a.bits_out[wi + (long)m * a.T * HW] = word;
         }
       }
       if (!ok) continue;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, HPVG_CONV_WGS(MB, NB)) void conv_mfma_kernel(c
       if constexpr (VAR == VAR_MASK) {
         if (a.mask_bits) {
 #pragma unroll
-          for (int m = 0; m < MB; ++m) mword[m] = (mb0 + m) * 32 < a.Cout ? a.mask_bits[wi + m] : 0u;
+          for (int m = 0; m < MB; ++m) mword[m] = (mb0 + m) * 32 < a.Cout ? a.mask_bits[wi + (long)m * a.T * HW] : 0u;
         }
       }
 #pragma unroll
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const ConvFwdArgs a, in
     for (int e = 0; e < 16; ++e) v[e] += src[e * 256];
   }
   const long sp = (long)tc.t * HW + (long)gh * a.W + gw;
-  const long wi = ((long)tc.b * a.T * HW + sp) * a.mbtot + tc.mb0 + m;
+  const long wi = ((long)tc.b * a.mbtot + tc.mb0 + m) * a.T * HW + sp;
   const unsigned mword = a.mask_bits ? a.mask_bits[wi] : 0u;
   unsigned word = 0;
 #pragma unroll
@@ -1576,7 +1576,8 @@ int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const 
                        Cout, T, H, W, KT, stream);
 }
 
-// number of 32-bit words of the 1-bit LeakyReLU mask of a [B][C][T][H][W] activation: [B][T*H*W][ceil(C/32)]
+// number of 32-bit words of the 1-bit LeakyReLU mask of a [B][C][T][H][W] activation: [B][ceil(C/32)][T*H*W] (position fastest:
+// the lanes of a wave hold neighbouring positions, so the word stores / loads of every conv kernel's epilogue are contiguous)
 size_t hpvg_conv_mask_words(int B, int C, int T, int H, int W) { return (size_t)B * T * H * W * hpvg_cdiv(C, 32); }
 
 // y = conv(x) (+bias) with the LeakyReLU sign mask in 1-bit form: `bits_out` (with out_lrelu; written for the consumer's

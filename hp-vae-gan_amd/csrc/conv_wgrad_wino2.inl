@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
   // the patch needs to find the rows again
   int pt_sd = -1, pt_sx = -1, pt_h0 = 0;
   bool pt_tok = false;
+  bool st_tok = false;      // the staged tile's input plane lies inside the clip (= it has work for this time tap)
   const float* pt_dyb = nullptr;
   const float* pt_xb = nullptr;
   auto setup = [&](int tile) {
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     decode(tile, b, t, th_i, tw_i);
     const int tt = t + dt - pt;
     const bool tok = tt >= 0 && tt < a.T;
+    st_tok = tok;
     const int h0 = th_i * a.Th, w0 = tw_i * Tw;
     const float* dyb = a.dy + (((long)b * a.Cout + ob * 64 + wave) * a.T + t) * HW;
     const float* xb = a.x + (((long)b * a.Cin + cb * 64 + wave) * a.T + (tok ? tt : 0)) * HW;
@@ -178,12 +180,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       }
     }
   };
-  auto tile_has_work = [&](int tile) __attribute__((always_inline)) -> bool {
-    int b, t, th_i, tw_i;
-    decode(tile, b, t, th_i, tw_i);
-    const int tt = t + dt - pt;
-    return tt >= 0 && tt < a.T;
-  };
   float* dma_d = lds;
   float* dma_x = lds;
   auto dma_begin = [&](float* buf) {
@@ -233,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 
   const int nsteps = a.QK >> 3;  // K-loop iterations: two quads = 8 positions = ONE MFMA k-step per point
   int cur = 0;
+  bool cur_tok = st_tok;      // (set by the first tile's setup)
   for (; tile < ntiles; tile += nslot) {
     const int next = tile + nslot;
     const bool have_next = next < ntiles;
@@ -250,7 +247,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 #ifdef HPVG_ABLW2_NOMMA
     if (false) {   // development ablation (timing only): everything but the K loop
 #else
-    if (active && tile_has_work(tile)) {
+    const bool work = cur_tok;
+    cur_tok = st_tok;           // (setup(next) above decoded the next tile)
+    if (active && work) {
 #endif
       // this lane's quad of step st: quad 2 st + half of the tile's row-major quad index (Tw / 2 quads per quad row, an even
       // count: both halves of a step sit in the same quad row)

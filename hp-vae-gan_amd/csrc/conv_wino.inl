@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
       const bool ok0 = q < a.L && ww < a.Tw && gh < a.H && gw < a.W;
       const bool ok1 = ok0 && gw + 1 < a.W;
       const long sp = (long)t * HW + (long)gh * a.W + gw;
-      const long wi = ((long)b * a.T * HW + sp) * a.mbtot + mt;   // mask word of the even position; the odd one: + mbtot
+      const long wi = ((long)b * a.mbtot + mt) * a.T * HW + sp;   // mask word of the even position; the odd one: + 1
       if constexpr (VAR == VAR_BITS) {
         unsigned word0 = 0, word1 = 0;
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
         word1 |= (unsigned)__shfl_xor((int)word1, 32, 64);
         if (half == 0 && mt_ok) {
           if (ok0) a.bits_out[wi] = word0;
-          if (ok1) a.bits_out[wi + a.mbtot] = word1;
+          if (ok1) a.bits_out[wi + 1] = word1;
         }
       }
       if (!ok0) continue;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvFwdArgs a) 
       if constexpr (VAR == VAR_MASK) {
         if (a.mask_bits && mt_ok) {
           mword0 = a.mask_bits[wi];
-          if (ok1) mword1 = a.mask_bits[wi + a.mbtot];
+          if (ok1) mword1 = a.mask_bits[wi + 1];
         }
       }
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_wino_fixup_kernel(const ConvFwdArgs 
     for (int e = 0; e < 16; ++e) v[e] += src[e * 256];
   }
   const long sp = (long)tc.t * HW + (long)gh * a.W + gw;
-  const long wi = ((long)tc.b * a.T * HW + sp) * a.mbtot + mt;
+  const long wi = ((long)tc.b * a.mbtot + mt) * a.T * HW + sp;
   const unsigned mword = a.mask_bits ? a.mask_bits[wi] : 0u;
   unsigned word = 0;
 #pragma unroll

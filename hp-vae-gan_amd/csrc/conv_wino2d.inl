@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
       const long HW = (long)HWp;
       const bool r0ok = c_vq && c_h < a.H, r1ok = c_vq && c_h + 1 < a.H;
       const long sp0 = (long)c_t * HW + (long)c_h * W + c_w;
-      const long wi0 = ((long)c_b * a.T * HW + sp0) * a.mbreal + mt;      // mask word of (h, w); (h, w+1): + mbreal; row h+1: + W*mbreal
+      const long wi0 = ((long)c_b * a.mbreal + mt) * a.T * HW + sp0;      // mask word of (h, w); (h, w+1): + 1; row h+1: + W
       unsigned wrd[4] = {0u, 0u, 0u, 0u};
       unsigned mwd[4] = {0u, 0u, 0u, 0u};
       // every load of the epilogue is issued up front (one latency per tile, not one per channel row: nothing else runs on
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
           const long wmax = (long)a.B * a.T * HW * a.mbreal - 1;      // clamp: lanes without a valid position read a valid word
           const long w0 = mt_ok ? wi0 : 0;
           mwd[0] = a.mask_bits[r0ok ? w0 : 0];
-          mwd[1] = a.mask_bits[r0ok ? w0 + a.mbreal : 0];
-          mwd[2] = a.mask_bits[r1ok ? (w0 + (long)W * a.mbreal < wmax ? w0 + (long)W * a.mbreal : wmax) : 0];
-          mwd[3] = a.mask_bits[r1ok ? (w0 + (long)(W + 1) * a.mbreal < wmax ? w0 + (long)(W + 1) * a.mbreal : wmax) : 0];
+          mwd[1] = a.mask_bits[r0ok ? w0 + 1 : 0];
+          mwd[2] = a.mask_bits[r1ok ? (w0 + W < wmax ? w0 + W : wmax) : 0];
+          mwd[3] = a.mask_bits[r1ok ? (w0 + W + 1 < wmax ? w0 + W + 1 : wmax) : 0];
         }
       }
       const bool lrelu = a.out_lrelu != 0;
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2d_kernel(const Wino2Args a) 
 #pragma unroll
         for (int p = 0; p < 4; ++p) wrd[p] |= (unsigned)__shfl_xor((int)wrd[p], 32, 64);   // the other half-wave's channels
         if (half == 0 && mt_ok) {
-          if (r0ok) { a.bits_out[wi0] = wrd[0]; a.bits_out[wi0 + a.mbreal] = wrd[1]; }
-          if (r1ok) { a.bits_out[wi0 + (long)W * a.mbreal] = wrd[2]; a.bits_out[wi0 + (long)(W + 1) * a.mbreal] = wrd[3]; }
+          if (r0ok) { a.bits_out[wi0] = wrd[0]; a.bits_out[wi0 + 1] = wrd[1]; }
+          if (r1ok) { a.bits_out[wi0 + W] = wrd[2]; a.bits_out[wi0 + W + 1] = wrd[3]; }
         }
       }
     }

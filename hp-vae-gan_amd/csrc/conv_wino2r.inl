@@ -363,25 +363,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       // the exchange (one wave per SIMD: nothing else would hide it)
       const int mt = c_yb * 2 + mw;
       const bool mt_ok = mt * 32 < a.Cout;
+      // (opaque per tile: hipcc otherwise hoists the 16 channels' 64-bit output offsets out of the tile loop as invariants,
+      // spills them around the K loop and reloads them from scratch here - ~30 dependent reloads per tile: the bit-mask variants
+      // lost 4-7 % to it)
+      int half_e = half;
+      asm volatile("" : "+v"(half_e));
       const long HW = (long)HWp;
       const bool r0ok = c_vq && c_h < a.H, r1ok = c_vq && c_h + 1 < a.H;
       const long sp0 = (long)c_t * HW + (long)c_h * W + c_w;
-      const long wi0 = ((long)c_b * a.T * HW + sp0) * a.mbreal + mt;      // mask word of (h, w); (h, w+1): + mbreal; row h+1: + W*mbreal
+      const long wi0 = ((long)c_b * a.mbreal + mt) * a.T * HW + sp0;      // mask word of (h, w); (h, w+1): + 1; row h+1: + W
       unsigned wrd[4] = {0u, 0u, 0u, 0u};
       unsigned mwd[4] = {0u, 0u, 0u, 0u};
       float bias_r[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int co = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half_e;
         bias_r[e] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
       }
       if constexpr (VAR == VAR_MASK) {
         const long wmax = (long)a.B * a.T * HW * a.mbreal - 1;      // clamp: lanes without a valid position read a valid word
         const long w0 = mt_ok ? wi0 : 0;
-        mwd[0] = a.mask_bits[r0ok ? w0 : 0];
-        mwd[1] = a.mask_bits[r0ok ? w0 + a.mbreal : 0];
-        mwd[2] = a.mask_bits[r1ok ? (w0 + (long)W * a.mbreal < wmax ? w0 + (long)W * a.mbreal : wmax) : 0];
-        mwd[3] = a.mask_bits[r1ok ? (w0 + (long)(W + 1) * a.mbreal < wmax ? w0 + (long)(W + 1) * a.mbreal : wmax) : 0];
+        // (position-fastest words: a lane's two columns are one aligned 8-byte load - w0 is even - and the lanes' loads contiguous)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 m01 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r0ok ? w0 : 0));
+        const u32x2 m23 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r1ok ? (w0 + W + 1 <= wmax ? w0 + W : 0) : 0));
+        mwd[0] = m01[0]; mwd[1] = m01[1]; mwd[2] = m23[0]; mwd[3] = m23[1];
       }
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       const bool lrelu = a.out_lrelu != 0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int shb = (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int shb = (e & 3) + 8 * (e >> 2) + 4 * half_e;
         const int co = mt * 32 + shb;
         float yv[4];
         yv[0] = y0[e][0];
@@ -476,8 +482,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #pragma unroll
         for (int p = 0; p < 4; ++p) wrd[p] |= (unsigned)__shfl_xor((int)wrd[p], 32, 64);   // the other half-wave's channels
         if (half == 0 && mt_ok) {
-          if (r0ok) { a.bits_out[wi0] = wrd[0]; a.bits_out[wi0 + a.mbreal] = wrd[1]; }
-          if (r1ok) { a.bits_out[wi0 + (long)W * a.mbreal] = wrd[2]; a.bits_out[wi0 + (long)(W + 1) * a.mbreal] = wrd[3]; }
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          if (r0ok) { u32x2 v2; v2[0] = wrd[0]; v2[1] = wrd[1]; *reinterpret_cast<u32x2*>(a.bits_out + wi0) = v2; }
+          if (r1ok) { u32x2 v2; v2[0] = wrd[2]; v2[1] = wrd[3]; *reinterpret_cast<u32x2*>(a.bits_out + wi0 + W) = v2; }
         }
       }
     }

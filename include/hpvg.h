@@ -60,7 +60,7 @@ size_t hpvg_conv_fwd_ws_bytes(int B, int Cin, int Cout, int T, int H, int W, int
 int hpvg_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* in_scale, const float* in_shift,
                       int in_lrelu, float* y, int out_lrelu, const float* out_mask, void* ws, size_t ws_bytes, int B, int Cin,
                       int Cout, int T, int H, int W, int KT, void* stream);
-/* The same conv with the LeakyReLU sign mask in 1-BIT form ([B][T*H*W][ceil(C/32)] words, bit c%32 of word c/32 = activation
+/* The same conv with the LeakyReLU sign mask in 1-BIT form ([B][ceil(C/32)][T*H*W] words, bit c%32 of word c/32 = activation
  * of channel c > 0; hpvg_conv_mask_words() of them): `bits_out` (nullable) is written by an out_lrelu epilogue for the
  * backward-data conv of the layer that consumes the activation, which passes it as `mask_bits` (nullable; instead of the
  * fp32 `out_mask` of hpvg_conv_fwd_f32: 8 mask loads per tile and lane instead of 128).  Cout > 4 only. */

@@ -164,10 +164,10 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
         assert bool(((sa == sb) | ~far).all())
         assert res[wm]["bits"].numel() == cw
         # bits written by the Winograd epilogue decode to the sign of its own output
-        bw = res[wm]["bits"].view(B, -1, mt).cpu()
+        bw = res[wm]["bits"].view(B, mt, -1).cpu()
         yw = res[wm]["ya"].reshape(B, Cout, -1).cpu()
         for c in (0, Cout // 2, Cout - 1):
-            got = (bw[:, :, c // 32] >> (c % 32)) & 1
+            got = (bw[:, c // 32, :] >> (c % 32)) & 1
             assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
 
 
@@ -215,10 +215,10 @@ def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, win
     for k in ("y", "dx", "ya", "dxm_f32"):
         assert_close(res[5][k], res[0][k], 3e-5, "wino2d-vs-direct." + k)
     mt = (Cout + 31) // 32
-    bw = res[5]["bits"].view(B, -1, mt).cpu()
+    bw = res[5]["bits"].view(B, mt, -1).cpu()
     yw = res[5]["ya"].reshape(B, Cout, -1).cpu()
     for c in (0, Cout // 2, Cout - 1):
-        got = (bw[:, :, c // 32] >> (c % 32)) & 1
+        got = (bw[:, c // 32, :] >> (c % 32)) & 1
         assert bool((got.bool() == (yw[:, c] > 0)).all()), "bits of channel %d" % c
 
 

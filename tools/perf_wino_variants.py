@@ -16,7 +16,8 @@ for mode in (6,5):
     lib.hpvg_conv_wino_config(mode,-1)
     ya,bits = ops.conv_fwd_raw(x,w,b,out_lrelu=True,want_bits=True)
     t_plain = bench(lambda: ops.conv_fwd_raw(x,w,b))
+    t_lrelu = bench(lambda: ops.conv_fwd_raw(x,w,b,out_lrelu=True))
     t_bits = bench(lambda: ops.conv_fwd_raw(x,w,b,out_lrelu=True,want_bits=True))
     t_mask = bench(lambda: ops.conv_fwd_raw(x,w,None,flip=True,mask_bits=bits))
     t_maskf = bench(lambda: ops.conv_fwd_raw(x,w,None,flip=True,out_mask=x))
-    print((B,T,H,W),'mode',mode,'plain %.4f bits %.4f mask_bits %.4f mask_f32 %.4f'%(t_plain,t_bits,t_mask,t_maskf))
+    print((B,T,H,W),'mode',mode,'plain %.4f lrelu %.4f bits %.4f mask_bits %.4f mask_f32 %.4f'%(t_plain,t_lrelu,t_bits,t_mask,t_maskf))
