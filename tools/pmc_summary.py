@@ -44,7 +44,7 @@ if json_out:
     if family == "conv_fwd":
         # the kernel the library runs the shape on (largest launch of the profiled tool = the full-resolution one): two-axis
         # Winograd (plain instance; whole tiles or its own stream-K tail) - else one-axis + fix-up - else direct + fix-up
-        parts = [biggest(lambda n: "conv_wino2d_kernel<0" in n)]
+        parts = [biggest(lambda n: "conv_wino2r_kernel<0" in n or "conv_wino2d_kernel<0" in n)]
         if parts[0] is None:
             wino = biggest(lambda n: "conv_wino_kernel<" in n and ", 0, " in n)
             parts = [wino, biggest(lambda n: "conv_wino_fixup_kernel" in n)] if wino else \
