@@ -54,7 +54,7 @@ if json_out:
     elif family == "weight_gradient":
         main = biggest(lambda n: "conv_wgradw2_kernel" in n) or biggest(lambda n: "conv_wgradw_kernel" in n) or \
             biggest(lambda n: "conv_wgrad3_kernel" in n) or biggest(lambda n: "conv_wgrad_kernel" in n)
-        red = main[0].split("<")[0].replace("_kernel", "_reduce_kernel")
+        red = main[0].split("<")[0].replace("void ", "").replace("_kernel", "_reduce_kernel")
         parts = [main, biggest(lambda n: red in n)]
     else:
         raise SystemExit("unknown family " + family)
