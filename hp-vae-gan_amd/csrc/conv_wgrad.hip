@@ -1253,11 +1253,10 @@ inline bool wgradw_wanted(const WPlan& p, int B, int Cin, int Cout, int T, int H
 }
 
 // Tile plan of conv_wgradw2_kernel (Winograd over H and W): the 16-byte staging form with an EVEN tile height (rows of quads)
-// and its K loop's cost (16 MFMAs per two quads = 8 positions).  W must be even (W = 2 mod 4: the kernel patches the one group
-// per row that straddles the right border).
+// and its K loop's cost (16 MFMAs per two quads = 8 positions).  Any W (W % 4 != 0: the kernel patches the one group per row
+// that straddles the right border).
 WPlan plan_wgradw2_search(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   WPlan best{};
-  if (W % 2 != 0) return best;
   double best_cost = 1e300;
   const int nob = hpvg_cdiv(Cout, 64), ncb = hpvg_cdiv(Cin, 64);
   int prev_tw = 0;
@@ -1589,9 +1588,9 @@ static int bwd_weight_impl(const float* dy, const float* x, const float* in_scal
     hipLaunchKernelGGL((conv_wgradw2_kernel<K, D, X, TWC, ST>), grid, dim3(256), p2.lds, s, a);                        \
   }
       // (the 16-column band - the tile of the large launches - has its row strides as immediates: one address register per
-      // operand; W = 2 (mod 4) runs the instance that patches the straddling groups)
+      // operand; W % 4 != 0 runs the instance that patches the straddling groups)
 #define HPVG_W2_PICK(K)                                                                                                \
-  if (W & 2) {                                                                                                         \
+  if (W & 3) {                                                                                                         \
     if (gjd == 1 && gjx == 1 && p2.Tw == 16) HPVG_W2_LAUNCH(K, 1, 1, 16, true)                                         \
     else if (gjd == 1 && gjx == 1) HPVG_W2_LAUNCH(K, 1, 1, 0, true)                                                    \
     else if (gjd == 1) HPVG_W2_LAUNCH(K, 1, 2, 0, true)                                                                \
@@ -1784,7 +1783,7 @@ int hpvg_channel_sum_f32(const float* x, float* out, int accumulate, void* ws, s
 // wide layer on a Winograd kernel; the two-axis one where wgradw2_wanted's size rule picks it), 2 = every wide layer, 3 = every
 // wide layer with the 4-byte staging form only (2 and below: the 16-byte form where the width allows it, unless
 // HPVG_WGRADW_G16=0), 4 = every wide layer, the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis
-// kernel (conv_wgradw2_kernel) wherever it can run (even W); 6 = the one-axis kernel only; a negative mode only queries.
+// kernel (conv_wgradw2_kernel) on every wide layer; 6 = the one-axis kernel only; a negative mode only queries.
 // Returns the mode in force.
 int hpvg_conv_bwd_weight_wino_config(int mode) {
   (void)wgradw_wanted(WPlan{}, 1, 8, 8, 1, 1, 1, 1);   // settle the defaults

@@ -22,9 +22,12 @@
 // scheme of conv_wino2d_kernel): slot 0 the LDS reads of the next step's operands, 3 the vertical pass of its dY quad, 4-7 the
 // vertical pass of its input patch, 8-11 the horizontal pass, 12-15 the horizontal pass of the dY quad, 1 / 5 / 9 (/ 13) an
 // LDS-DMA piece of the next tile.
-// Widths: W even.  W = 2 (mod 4): the one 16-byte group per row that straddles the right image border (columns W - 2 .. W + 1) is
-// zero-sourced like every group outside, and the wave that stages the channel patches its two valid floats in with an ordinary
-// in-bounds 8-byte load + LDS write after the tile's pieces have landed (border-band tiles only: ~4 loads and 8 LDS writes per
+// Widths: any.  The LDS tile is laid out by TILE columns (band origins are multiples of 4), so the 8-byte operand pairs are
+// aligned whatever the row pitch W; the 16-byte global pieces need only 4-byte alignment (tools/glds16_probe.hip).  W % 4 != 0:
+// the one 16-byte group per row that straddles the right image border (it holds the row's last W % 4 columns) is zero-sourced
+// like every group outside, and the wave that stages the channel patches its 1-3 valid floats in with ordinary in-bounds
+// loads + LDS writes after the tile's pieces have landed; an odd W's last quad column has its second column outside the image
+// (zeros on both operands) (border-band tiles only: ~4 loads and 8 LDS writes per
 // wave and tile, behind the same wait the barrier needs anyway) - nothing is ever read past a row or a tensor.
 // Tiles: Th x Tw output positions, Th even, Tw and the band origins multiples of 4: the 16-byte staging form
 // of conv_wgradw_kernel - a dY row is Tw floats, an X row Tw + 8 floats from column w0 - 4 one float into its channel row, so
@@ -34,7 +37,7 @@
 // a.order: the walk over the tiles.  0: time-major (tile = ((b * nth + th) * ntw + tw) * T + t: the slots of an XCD hold one
 // spatial tile at neighbouring t); 1: plane-major (tile = ((b * T + t) * nth + th) * ntw + tw: the slots of an XCD hold
 // neighbouring tiles of one plane, which share halo columns / rows and the other halves of their 128-byte lines in that XCD's L2)
-// STRAD: W = 2 (mod 4) - a separate instance, so that the usual one carries none of the patch code (present but never executed it
+// STRAD: W % 4 != 0 - a separate instance, so that the usual one carries none of the patch code (present but never executed it
 // cost the stage-9 launch 3 %: registers)
 template <int KT, int NJD, int NJX, int TWC, bool STRAD>
 __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a) {
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     const float* dyb = a.dy + (((long)b * a.Cout + ob * 64 + wave) * a.T + t) * HW;
     const float* xb = a.x + (((long)b * a.Cin + cb * 64 + wave) * a.T + (tok ? tt : 0)) * HW;
     if constexpr (STRAD) {
-      const int sd = a.W - 2 - w0, sx = a.W - 2 - (w0 - 4);
+      const int gs = a.W - (a.W & 3);                 // first column of the group that holds the row's last W % 4 columns
+      const int sd = gs - w0, sx = gs - (w0 - 4);
       pt_sd = (sd >= 0 && sd < Tw) ? sd : -1;
       pt_sx = (sx >= 0 && sx < Tw + 8) ? sx : -1;
       pt_h0 = h0; pt_tok = tok; pt_dyb = dyb; pt_xb = xb;
@@ -172,11 +176,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       const bool live = id < NCH * nrow && gh >= 0 && gh < a.H &&
                         (isd ? (pt_sd >= 0 && ch < no) : (pt_sx >= 0 && ch < nc && pt_tok));
       if (live) {
-        const float* src = (isd ? pt_dyb : pt_xb) + (long)k * NW * cstride + (long)gh * a.W + (a.W - 2);
-        const wf32x2a v = *reinterpret_cast<const wf32x2a*>(src);
+        const int nv = a.W & 3;                        // 1, 2 or 3 valid floats
+        const float* src = (isd ? pt_dyb : pt_xb) + (long)k * NW * cstride + (long)gh * a.W + (a.W - nv);
         float* dst = isd ? buf + ch * DS + hh * Tw + pt_sd : buf + 64 * DS + ch * XS + 1 + hh * RS + pt_sx;
-        dst[0] = v[0];
-        dst[1] = v[1];
+        const float v0 = src[0];
+        const float v1 = nv > 1 ? src[1] : 0.f;
+        const float v2 = nv > 2 ? src[2] : 0.f;
+        dst[0] = v0;
+        if (nv > 1) dst[1] = v1;
+        if (nv > 2) dst[2] = v2;
       }
     }
   };

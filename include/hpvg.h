@@ -108,7 +108,7 @@ int hpvg_conv_bwd_weight_kernel_kind(int B, int Cin, int Cout, int T, int H, int
  * 3 = every wide layer without the 16-byte staging form (widths that are multiples of 4 otherwise get it), 4 = every
  * wide layer with the 16-byte form on four waves instead of eight; 5 = every wide layer, the TWO-axis kernel (the transpose
  * of F(2x2,3x3) over H and W: 16 products per 2 x 2 output positions and dt instead of 36, 4/9 of the direct matrix-core work)
- * wherever it can run (even W; by default it takes the launches whose workgroups walk enough tiles), 6 = every wide layer,
+ * (any width; by default it takes the launches whose workgroups walk enough tiles), 6 = every wide layer,
  * the one-axis kernel only (2, 3, 4 also keep to the one-axis kernel); negative = query.  Returns the mode in force.  Host only. */
 int hpvg_conv_bwd_weight_wino_config(int mode);
 /* The weight gradient and the conv's bias gradient db[o] (+)= sum_{b,positions} dy[b][o] from ONE launch, for the layers

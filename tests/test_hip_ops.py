@@ -258,9 +258,9 @@ def test_conv_weight_gradient_winograd_kernel_against_direct_kernels_and_oracle(
         bbase = _rand(Cout, seed=35).to(DEV)
         for mode in (2, 3, 4, 5, 0):
             assert lib.hpvg_conv_bwd_weight_wino_config(mode) == mode
-            if Cin > 4 and Cout > 4:   # mode 5 = the two-axis kernel wherever W is even, the one-axis kernel elsewhere
+            if Cin > 4 and Cout > 4:   # mode 5 = the two-axis kernel on every wide layer
                 kind = lib.hpvg_conv_bwd_weight_kernel_kind(B, Cin, Cout, sp[0] if nd == 3 else 1, sp[-2], sp[-1], 3 if nd == 3 else 1)
-                assert kind == ((3 if sp[-1] % 2 == 0 else 2) if mode == 5 else (2 if mode >= 2 else kind)) and (mode or kind in (0, 1))
+                assert kind == (3 if mode == 5 else (2 if mode >= 2 else kind)) and (mode or kind in (0, 1))
             dw = ops.conv_bwd_weight_raw(gyd, xd, w.shape)
             acc = base.clone()
             assert ops.conv_bwd_weight_raw(gyd, xd, w.shape, into=acc) is None

@@ -17,7 +17,7 @@ def test_wide_train_step_matches_reference(fname):
 
 # hpvg_conv_wino_config modes: 1 = by size (the default), 5 = the two-axis Winograd kernel wherever it can run (even W),
 # 3 / 4 = the one-axis kernel with the rows-as-in-memory / halo'd-band staging form, 0 = the direct kernel;
-# hpvg_conv_bwd_weight_wino_config modes: 1 = default, 5 = the two-axis Winograd kernel wherever W is even, 2 = the one-axis kernel
+# hpvg_conv_bwd_weight_wino_config modes: 1 = default, 5 = the two-axis Winograd kernel, 2 = the one-axis kernel
 # on every wide layer, 4 = its 16-byte form on four waves, 3 = its 4-byte form only, 0 = the direct weight-gradient kernels
 CONV_MODES = [1, 5, 3, 4, 0]
 WGRAD_MODES = [1, 5, 2, 4, 3, 0]
