@@ -1270,12 +1270,15 @@ inline bool conv_use_wino(int B, int Cin, int Cout, int T, int H, int W, int KT,
 
 // The two-axis Winograd kernel (conv_wino2d.inl): where it can run and where it is taken.  g_wino2d: 0 = by size, 1 = never,
 // 2 = wherever it can run (hpvg_conv_wino_config modes 5 / 6 set 2 / 1).
+// HPVG_WINO2R=0 keeps the first-generation kernel (every wave all 16 points of one block: conv_wino2d_kernel); default: the
+// points split over the waves by row (conv_wino2r_kernel: half the input-transform instructions and U loads per MFMA)
+static const bool g_wino2r = [] { const char* e = getenv("HPVG_WINO2R"); return !e || atoi(e) != 0; }();
 int g_wino2d = 0;
 struct W2Geom { int Cq, R, ntq, tqw, gridy, nsc, ntl; bool ok; };
 inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   W2Geom q{};
-  if (!conv_is_wino2d(Cin, Cout, KT) || (W & 1) || W < 2 || (long)H * W < 4) return q;
-  q.Cq = W / 2;
+  if (!conv_is_wino2d(Cin, Cout, KT) || ((W & 1) && !g_wino2r) || W < 2 || (long)H * W < 4) return q;   // (odd W: conv_wino2r_kernel's ODD instance)
+  q.Cq = (W + 1) / 2;
   q.R = hpvg_cdiv(H, 2);
   const int nq = q.R * q.Cq;
   q.ntq = hpvg_cdiv(nq, 64);                            // tiles per plane: 64 consecutive quads each
@@ -1300,23 +1303,21 @@ inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT)
   q.ok = true;
   return q;
 }
-// Taken by size where it was measured to win.  Whole tiles, one workgroup per CU and no stream-K want enough tiles to fill the
-// chip about twice.  Round 3, conv_wino2r_kernel against the one-axis kernel + fix-up (tools/perf_wino2.py,
-// profiles/r03_perf_wino2r_sizes.txt; rounds = tiles / 256): 0.94 rounds x1.00, 1.88 x1.11, 2.02 x1.08, 3.23 x1.10 (H * W = 2 mod
-// 4: the TAIL instance) / x1.17, 4.05 x1.18, 4.84 x1.22, 4.98 x1.37, 6.45 x1.17, 14.6 x1.33.  (Round 2, conv_wino2d_kernel:
-// 3.2 rounds lost 4 %, the rule was three rounds filled to 88 %.)  Rule: at least 1.8 rounds.
+// Taken by size where it was measured to win.  Whole tiles, one workgroup per CU, no stream-K: a launch takes ceil(tiles / 256)
+// rounds of ~72 us (64 -> 64), the one-axis kernel + fix-up ~100-120 us per 256 tiles' worth of work (more below one round).
+// Round 3, conv_wino2r_kernel against the one-axis kernel (tools/perf_wino2.py, profiles/r03_perf_wino2r_sizes.txt; rounds =
+// tiles / 256): 0.35 x0.94, 0.59 x1.12, 0.70 x1.48, 0.94 x1.43, 1.17 x0.94, 1.88 x1.36, 1.97 x1.07 (odd W), 3.23 x1.18-1.21,
+// 3.94 x1.13 (odd W), 4.98 x1.37, 6.45 x1.31, 14.6 x1.33.  (Before the plane-end patch ran on twelve lanes at once the TAIL
+// instance - H * W % 4 != 0 - lost below two rounds; round 2's conv_wino2d_kernel wanted three rounds filled to 88 %.)
+// Rule: the last round at least 60 % full.
 inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
   if (g_wino2d == 2) return true;
-  return (long)q.ntl * 10 >= 18L * HPVG_NUM_CU;
+  const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
+  return (long)q.ntl * 10 >= 6L * rounds * HPVG_NUM_CU;
 }
-// HPVG_WINO2R=0 keeps the first-generation kernel (every wave all 16 points of one block: conv_wino2d_kernel); default: the
-// points split over the waves by row (conv_wino2r_kernel: half the input-transform instructions and U loads per MFMA)
-static const bool g_wino2r = [] { const char* e = getenv("HPVG_WINO2R"); return !e || atoi(e) != 0; }();
-template <int VAR, bool TAIL>
-int launch_wino2d_inst(const Wino2Args& a, hipStream_t s) {
-  static bool attr_set = false;
-  auto kern = g_wino2r ? conv_wino2r_kernel<VAR, TAIL> : conv_wino2d_kernel<VAR, TAIL>;
+template <typename K>
+int launch_wino2d_kern(K kern, bool& attr_set, const Wino2Args& a, hipStream_t s) {
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       (void)hipGetLastError();
@@ -1325,6 +1326,13 @@ int launch_wino2d_inst(const Wino2Args& a, hipStream_t s) {
   const int S = a.ntl < HPVG_NUM_CU ? a.ntl : HPVG_NUM_CU;
   hipLaunchKernelGGL(kern, dim3(S), dim3(256), (size_t)3 * 12 * W2_PL * sizeof(float), s, a);   // three input buffers
   return hpvg_launch_status();
+}
+template <int VAR, bool TAIL>
+int launch_wino2d_inst(const Wino2Args& a, hipStream_t s) {
+  static bool attr_r = false, attr_o = false, attr_d = false;
+  if (a.W & 1) return launch_wino2d_kern(conv_wino2r_kernel<VAR, TAIL, true>, attr_o, a, s);    // (only the row-split kernel has an odd-W instance)
+  if (g_wino2r) return launch_wino2d_kern(conv_wino2r_kernel<VAR, TAIL, false>, attr_r, a, s);
+  return launch_wino2d_kern(conv_wino2d_kernel<VAR, TAIL>, attr_d, a, s);
 }
 
 template <int VAR>

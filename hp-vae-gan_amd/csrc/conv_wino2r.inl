@@ -17,6 +17,10 @@
 // the two input buffers that are idle at that point (96 KB, conflict-free 16-byte writes / reads, two barriers per tile:
 // ~1.5 % of a tile's 1536 MFMAs), and finishes the block it owns (wave = quad half * 2 + m-tile, as in conv_wino2d_kernel)
 // with the unchanged epilogue.
+// ODD (a separate instance): odd W.  The LDS image of a plane is a verbatim copy of memory, so with an odd row pitch every other
+// patch row starts at an odd float: the rows are read with four ds_read_b32 each instead of two ds_read_b64 (LDS reads are free
+// beside the MFMAs), the last quad column's input columns W, W + 1 are zeroed by a third border factor (f2), its second output
+// column is not stored, and the 1-bit mask words are accessed one by one; the plane-end patch (TAIL) copies H * W % 4 floats.
 
 #define W2R_WAIT_A(N, S) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(au[S][0]), "+v"(au[S][1]) : : "memory")
 
@@ -31,7 +35,7 @@
 #define W2R_ABL_LOADA(D, O, B) w2_load_a(D, O, B)
 #endif
 
-template <int VAR, bool TAIL>
+template <int VAR, bool TAIL, bool ODD>
 __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -100,29 +104,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
   };
   // (the tile is decoded again inside the rare branch: keeping b / t of two tiles alive through the K loop for it cost the TAIL
   // instance its scalar registers - 24 v_readfirstlane and a scratch reload per item)
+  // Twelve lanes of the wave that owns the tail lane take one plane each (one load latency per item instead of twelve in a row:
+  // with the serial loop the plane's last tile took ~2.5x as long as the others - the whole launch when it is a single round,
+  // 18 % at stage 7); same wave as the lane that zero-filled the group (stage_zero), so the LDS writes stay in order.
   auto stage_tail = [&](int tile_, int tail_, int sc, int bf) __attribute__((always_inline)) {
     if (tail_ < 0) return;
-    if (tid == tail_) {
-      int qb, qt, tp, yb;
-      decode(tile_, qb, qt, tp, yb);
-      const char* p0 = reinterpret_cast<const char*>(a.x) + (((long)qb * a.Cin + (long)sc * 4) * a.T + (qt - 1)) * HWb;
-#pragma unroll 1
-      for (int pl = 0; pl < 12; ++pl) {
+    if ((tid >> 6) == (tail_ >> 6)) {
+      if (lane < 12) {
+        int qb, qt, tp, yb;
+        decode(tile_, qb, qt, tp, yb);
+        const int pl = lane;
         const int cc = pl / 3, dt = pl - 3 * cc;
         const int tt = qt + dt - 1;
         if (sc * 4 + cc < a.Cin && tt >= 0 && tt < a.T) {
-          const float* src = reinterpret_cast<const float*>(p0 + ((long)cc * a.T + dt) * HWb) + (HWp - 2);
+          const int nv = HWp & 3;                    // floats of the plane in its last group (2 for even W; 1 or 3 for odd H * W)
+          const float* src = reinterpret_cast<const float*>(a.x) + ((((long)qb * a.Cin + (long)sc * 4 + cc) * a.T + tt) * (long)HWp) + (HWp - nv);
           float* dst = xs + bf * BUFF + pl * PL + 1 + 4 * tail_;
-          dst[0] = src[0];
-          dst[1] = src[1];
+          const float v0 = src[0];
+          const float v1 = nv > 1 ? src[1] : 0.f;
+          const float v2 = nv > 2 ? src[2] : 0.f;
+          dst[0] = v0;
+          if (nv > 1) dst[1] = v1;
+          if (nv > 2) dst[2] = v2;
         }
       }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   };
 
   // how this lane reads the patch rows ra / rb of its TWO quads (one per quad half) and their image-border factors
-  struct ReadT { int ba[2], bb[2]; float f0[2], f3[2]; };
+  struct ReadT { int ba[2], bb[2]; float f0[2], f3[2], f2[2]; };
   int c_yb = 0, c_b = 0, c_t = 0, c_h = 0, c_w = 0;
   bool c_vq = false;
   auto read_setup = [&](int tile) __attribute__((always_inline)) -> ReadT {
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       q.bb[qh] = base + rb * W;
       q.f0[qh] = w == 0 ? 0.f : 1.f;
       q.f3[qh] = w + 2 >= W ? 0.f : 1.f;
+      q.f2[qh] = w + 1 >= W ? 0.f : 1.f;     // (odd W only: the last quad column's second column is outside the image)
     }
     return q;
   };
@@ -178,27 +190,49 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
   // what this kernel pays for); LDS reads issue in the MFMAs' shadow.  W2R_WAIT_RAW before the first use (form (ii) of
   // cdna_hip_programming.md 5.7: the destinations pass through the wait statement).
 #define W2R_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define W2R_DSREAD1(DST, ADDR, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W2R_LOAD_RAW(XA, XB, STEP)                                                              \
   {                                                                                             \
     constexpr int so_ = (((STEP) & 1) * 6 + ((STEP) >> 1)) * (PL / 2) * 8;                      \
-    W2R_DSREAD(rwa[0][0], (XA)[0], so_); W2R_DSREAD(rwa[0][1], (XA)[0], so_ + 8);               \
-    W2R_DSREAD(rwb[0][0], (XB)[0], so_); W2R_DSREAD(rwb[0][1], (XB)[0], so_ + 8);               \
-    W2R_DSREAD(rwa[1][0], (XA)[1], so_); W2R_DSREAD(rwa[1][1], (XA)[1], so_ + 8);               \
-    W2R_DSREAD(rwb[1][0], (XB)[1], so_); W2R_DSREAD(rwb[1][1], (XB)[1], so_ + 8);               \
+    if constexpr (!ODD) {                                                                       \
+      W2R_DSREAD(rwa[0][0], (XA)[0], so_); W2R_DSREAD(rwa[0][1], (XA)[0], so_ + 8);             \
+      W2R_DSREAD(rwb[0][0], (XB)[0], so_); W2R_DSREAD(rwb[0][1], (XB)[0], so_ + 8);             \
+      W2R_DSREAD(rwa[1][0], (XA)[1], so_); W2R_DSREAD(rwa[1][1], (XA)[1], so_ + 8);             \
+      W2R_DSREAD(rwb[1][0], (XB)[1], so_); W2R_DSREAD(rwb[1][1], (XB)[1], so_ + 8);             \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int qh_ = 0; qh_ < 2; ++qh_) {                                     \
+        W2R_DSREAD1(rfa[qh_][0], (XA)[qh_], so_); W2R_DSREAD1(rfa[qh_][1], (XA)[qh_], so_ + 4); \
+        W2R_DSREAD1(rfa[qh_][2], (XA)[qh_], so_ + 8); W2R_DSREAD1(rfa[qh_][3], (XA)[qh_], so_ + 12); \
+        W2R_DSREAD1(rfb[qh_][0], (XB)[qh_], so_); W2R_DSREAD1(rfb[qh_][1], (XB)[qh_], so_ + 4); \
+        W2R_DSREAD1(rfb[qh_][2], (XB)[qh_], so_ + 8); W2R_DSREAD1(rfb[qh_][3], (XB)[qh_], so_ + 12); \
+      }                                                                                         \
+    }                                                                                           \
   }
 #define W2R_WAIT_RAW()                                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rwa[0][0]), "+v"(rwa[0][1]), "+v"(rwa[1][0]), "+v"(rwa[1][1]),  \
-               "+v"(rwb[0][0]), "+v"(rwb[0][1]), "+v"(rwb[1][0]), "+v"(rwb[1][1]))
+  {                                                                                             \
+    if constexpr (!ODD)                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rwa[0][0]), "+v"(rwa[0][1]), "+v"(rwa[1][0]), "+v"(rwa[1][1]),  \
+                   "+v"(rwb[0][0]), "+v"(rwb[0][1]), "+v"(rwb[1][0]), "+v"(rwb[1][1]));         \
+    else                                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rfa[0][0]), "+v"(rfa[0][1]), "+v"(rfa[0][2]), "+v"(rfa[0][3]),  \
+                   "+v"(rfa[1][0]), "+v"(rfa[1][1]), "+v"(rfa[1][2]), "+v"(rfa[1][3]),          \
+                   "+v"(rfb[0][0]), "+v"(rfb[0][1]), "+v"(rfb[0][2]), "+v"(rfb[0][3]),          \
+                   "+v"(rfb[1][0]), "+v"(rfb[1][1]), "+v"(rfb[1][2]), "+v"(rfb[1][3]));         \
+  }
+#define W2R_RA(QH, C) (ODD ? rfa[QH][C] : rwa[QH][(C) >> 1][(C) & 1])
+#define W2R_RB(QH, C) (ODD ? rfb[QH][C] : rwb[QH][(C) >> 1][(C) & 1])
 // vertical pass of row ri, columns 2 P, 2 P + 1 of quad half QH
 #define W2R_VERT(QH, P)                                                                         \
   {                                                                                             \
-    tn[QH][2 * (P)] = __builtin_fmaf(sv, rwb[QH][P][0], rwa[QH][P][0]);                         \
-    tn[QH][2 * (P) + 1] = __builtin_fmaf(sv, rwb[QH][P][1], rwa[QH][P][1]);                     \
+    tn[QH][2 * (P)] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P)), W2R_RA(QH, 2 * (P)));             \
+    tn[QH][2 * (P) + 1] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P) + 1), W2R_RA(QH, 2 * (P) + 1)); \
   }
 // horizontal pass: points (ri, 0), (ri, 1) (P = 0) or (ri, 2), (ri, 3) (P = 1) with the image-border factors folded in
-#define W2R_HORZ(QH, P, OUT, F0, F3)                                                            \
+// (ODD: column 2 of the patch may lie outside the image as well: t2 is scaled by f2 first)
+#define W2R_HORZ(QH, P, OUT, F0, F3, F2)                                                        \
   {                                                                                             \
     if ((P) == 0) {                                                                             \
+      if constexpr (ODD) tn[QH][2] *= F2[QH];                                                   \
       OUT[QH][0] = __builtin_fmaf(F0[QH], tn[QH][0], -tn[QH][2]);                               \
       OUT[QH][1] = tn[QH][1] + tn[QH][2];                                                       \
     } else {                                                                                    \
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     }                                                                                           \
   }
   f32x2a rwa[2][2], rwb[2][2];
+  float rfa[2][4], rfb[2][4];                       // (ODD: the rows as four dwords)
   float vA[2][4], vB[2][4], tn[2][4];
 
   // ---- prologue: first item of the first tile (nothing to overlap with)
@@ -241,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     W2R_LOAD_RAW(xa0, xb0, 0)
     W2R_WAIT_RAW();
     W2R_VERT(0, 0) W2R_VERT(0, 1) W2R_VERT(1, 0) W2R_VERT(1, 1)
-    W2R_HORZ(0, 0, vA, rd_cur.f0, rd_cur.f3) W2R_HORZ(0, 1, vA, rd_cur.f0, rd_cur.f3)
-    W2R_HORZ(1, 0, vA, rd_cur.f0, rd_cur.f3) W2R_HORZ(1, 1, vA, rd_cur.f0, rd_cur.f3)
+    W2R_HORZ(0, 0, vA, rd_cur.f0, rd_cur.f3, rd_cur.f2) W2R_HORZ(0, 1, vA, rd_cur.f0, rd_cur.f3, rd_cur.f2)
+    W2R_HORZ(1, 0, vA, rd_cur.f0, rd_cur.f3, rd_cur.f2) W2R_HORZ(1, 1, vA, rd_cur.f0, rd_cur.f3, rd_cur.f2)
   }
 
   int bufsel = 0;
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     cmp_setup(tile);
     const char* abase_cur = reinterpret_cast<const char*>(a.wp) + ((long)((tile % a.gridy) * 2)) * 1024 + (long)ri * afrag;
     const char* abase_nxt = reinterpret_cast<const char*>(a.wp) + ((long)((ntile % a.gridy) * 2)) * 1024 + (long)ri * afrag;
-    float f0[2] = {rd_cur.f0[0], rd_cur.f0[1]}, f3[2] = {rd_cur.f3[0], rd_cur.f3[1]};
+    float f0[2] = {rd_cur.f0[0], rd_cur.f0[1]}, f3[2] = {rd_cur.f3[0], rd_cur.f3[1]}, f2[2] = {rd_cur.f2[0], rd_cur.f2[1]};
     int last_cb = 0;
 
     f32x16 acc[16];    // [(m-tile * 2 + quad half) * 4 + j]
@@ -277,7 +312,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       const int n_t = wrap ? st_nxt.t : st_cur.t;
       const char* anext = (wrap ? abase_nxt : abase_cur) + (long)nsc_i * ascstride;
       const unsigned ldsn = lds0 + (unsigned)((nb * BUFF + 1) * 4 + wave * 1024);
-      float nf0[2], nf3[2];
+      float nf0[2], nf3[2], nf2[2];
+      nf2[0] = wrap ? rd_nxt.f2[0] : f2[0]; nf2[1] = wrap ? rd_nxt.f2[1] : f2[1];
       nf0[0] = wrap ? rd_nxt.f0[0] : f0[0]; nf0[1] = wrap ? rd_nxt.f0[1] : f0[1];
       nf3[0] = wrap ? rd_nxt.f3[0] : f3[0]; nf3[1] = wrap ? rd_nxt.f3[1] : f3[1];
       // this item's row addresses (buffer cb) and the next item's (buffer nb; the next tile's geometry at a tile wrap)
@@ -318,8 +354,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     if ((K) == 0 && (STEP) == 5) W2R_LOAD_RAW(xan, xbn, 0)                                                         \
     if ((K) == 4) W2R_WAIT_RAW();                                                                                  \
     if ((K) >= 4 && (K) < 8) W2R_VERT((((K) - 4) >> 1) & 1, (K) & 1)                                                     \
-    if ((K) >= 8 && (K) < 12 && (STEP) < 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, f0, f3)                          \
-    if ((K) >= 8 && (K) < 12 && (STEP) == 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, nf0, nf3)                       \
+    if ((K) >= 8 && (K) < 12 && (STEP) < 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, f0, f3, f2)                          \
+    if ((K) >= 8 && (K) < 12 && (STEP) == 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, nf0, nf3, nf2)                       \
     if (((K) & 3) == 0 && (STEP) < 3) W2R_STAGE_ADDR((STEP) * 4 + ((K) >> 2))                                      \
     if (((K) & 3) == 1 && (STEP) < 3) W2R_ABL_STAGE((STEP) * 4 + ((K) >> 2))                                       \
     if ((K) >= 14) W2R_ABL_LOADA(au[STEP][(K) & 1], aoff, anext + (long)((STEP) * 4) * afrag + ((K) & 1) * 1024);  \
@@ -385,9 +421,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
         const long w0 = mt_ok ? wi0 : 0;
         // (position-fastest words: a lane's two columns are one aligned 8-byte load - w0 is even - and the lanes' loads contiguous)
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 m01 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r0ok ? w0 : 0));
-        const u32x2 m23 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r1ok ? (w0 + W + 1 <= wmax ? w0 + W : 0) : 0));
-        mwd[0] = m01[0]; mwd[1] = m01[1]; mwd[2] = m23[0]; mwd[3] = m23[1];
+        if constexpr (!ODD) {
+          const u32x2 m01 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r0ok ? w0 : 0));
+          const u32x2 m23 = *reinterpret_cast<const u32x2*>(a.mask_bits + (r1ok ? (w0 + W + 1 <= wmax ? w0 + W : 0) : 0));
+          mwd[0] = m01[0]; mwd[1] = m01[1]; mwd[2] = m23[0]; mwd[3] = m23[1];
+        } else {   // (odd row pitch: the pairs are not 8-byte aligned, the last quad column has one column only)
+          const bool c1 = c_w + 1 < W;
+          mwd[0] = a.mask_bits[r0ok ? w0 : 0];
+          mwd[1] = a.mask_bits[r0ok && c1 ? w0 + 1 : 0];
+          mwd[2] = a.mask_bits[r1ok ? w0 + W : 0];
+          mwd[3] = a.mask_bits[r1ok && c1 ? w0 + W + 1 : 0];
+        }
       }
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
@@ -467,15 +511,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #pragma unroll
           for (int p = 0; p < 4; ++p) yv[p] *= ((mwd[p] >> shb) & 1u) ? 1.f : HPVG_LRELU_SLOPE;
         }
-        if (cok && r0ok) {
-          f32x2u4 o2;
-          o2[0] = yv[0]; o2[1] = yv[1];
-          *reinterpret_cast<f32x2u4*>(a.y + oi) = o2;
-        }
-        if (cok && r1ok) {
-          f32x2u4 o2;
-          o2[0] = yv[2]; o2[1] = yv[3];
-          *reinterpret_cast<f32x2u4*>(a.y + oi + W) = o2;
+        if (!ODD || c_w + 1 < W) {
+          if (cok && r0ok) {
+            f32x2u4 o2;
+            o2[0] = yv[0]; o2[1] = yv[1];
+            *reinterpret_cast<f32x2u4*>(a.y + oi) = o2;
+          }
+          if (cok && r1ok) {
+            f32x2u4 o2;
+            o2[0] = yv[2]; o2[1] = yv[3];
+            *reinterpret_cast<f32x2u4*>(a.y + oi + W) = o2;
+          }
+        } else {   // (odd W, last quad column: one output column)
+          if (cok && r0ok) a.y[oi] = yv[0];
+          if (cok && r1ok) a.y[oi + W] = yv[2];
         }
       }
       if constexpr (VAR == VAR_BITS) {
@@ -483,8 +532,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
         for (int p = 0; p < 4; ++p) wrd[p] |= (unsigned)__shfl_xor((int)wrd[p], 32, 64);   // the other half-wave's channels
         if (half == 0 && mt_ok) {
           typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-          if (r0ok) { u32x2 v2; v2[0] = wrd[0]; v2[1] = wrd[1]; *reinterpret_cast<u32x2*>(a.bits_out + wi0) = v2; }
-          if (r1ok) { u32x2 v2; v2[0] = wrd[2]; v2[1] = wrd[3]; *reinterpret_cast<u32x2*>(a.bits_out + wi0 + W) = v2; }
+          if constexpr (!ODD) {
+            if (r0ok) { u32x2 v2; v2[0] = wrd[0]; v2[1] = wrd[1]; *reinterpret_cast<u32x2*>(a.bits_out + wi0) = v2; }
+            if (r1ok) { u32x2 v2; v2[0] = wrd[2]; v2[1] = wrd[3]; *reinterpret_cast<u32x2*>(a.bits_out + wi0 + W) = v2; }
+          } else {
+            const bool c1 = c_w + 1 < W;
+            if (r0ok) { a.bits_out[wi0] = wrd[0]; if (c1) a.bits_out[wi0 + 1] = wrd[1]; }
+            if (r1ok) { a.bits_out[wi0 + W] = wrd[2]; if (c1) a.bits_out[wi0 + W + 1] = wrd[3]; }
+          }
         }
       }
     }
@@ -498,5 +553,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #undef W2R_VERT
 #undef W2R_LOAD_RAW
 #undef W2R_DSREAD
+#undef W2R_DSREAD1
 #undef W2R_WAIT_RAW
+#undef W2R_RA
+#undef W2R_RB
 #undef W2R_WAIT_A

@@ -177,6 +177,10 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
     # H*W = 2 (mod 4): the 16-byte group at the end of a plane is patched in by the tile that stages it (stage_tail); with
     # several tiles per plane, tiny planes, the last plane of the tensor (nothing may be read past it) and an odd height
     (1, 64, 64, (3, 57, 102)), (2, 16, 40, (2, 3, 2)), (1, 64, 64, (5, 7, 6)), (2, 64, 64, (2, 91, 162)), (1, 64, 64, (3, 1, 2)),
+    # odd W (round 3: the ODD instance - dword LDS reads, a third border factor, one-column last quads, dword mask words):
+    # H * W = 1, 3 (mod 4) (the plane-end patch copies 1 or 3 floats) and even H, several tiles per plane, W = 3, ragged channels
+    (1, 64, 64, (2, 5, 7)), (2, 64, 64, (3, 36, 65)), (1, 64, 64, (2, 9, 129)), (1, 24, 40, (2, 3, 3)), (1, 64, 64, (3, 7, 5)),
+    (2, 64, 64, (2, 5, 9)), (1, 64, 64, (4, 18, 33)),
 ])
 def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
     """conv_wino2d_kernel (F(2x2, 3x3) over H and W, one workgroup per CU, software-pipelined with hand-counted waits;
