@@ -1309,11 +1309,13 @@ inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT)
 // tiles / 256): 0.35 x0.94, 0.59 x1.12, 0.70 x1.48, 0.94 x1.43, 1.17 x0.94, 1.88 x1.36, 1.97 x1.07 (odd W), 3.23 x1.18-1.21,
 // 3.94 x1.13 (odd W), 4.98 x1.37, 6.45 x1.31, 14.6 x1.33.  (Before the plane-end patch ran on twelve lanes at once the TAIL
 // instance - H * W % 4 != 0 - lost below two rounds; round 2's conv_wino2d_kernel wanted three rounds filled to 88 %.)
-// Rule: the last round at least 60 % full.
+// Rule: a single round from half a chip of tiles (the one-axis kernel pays its fix-up launch and stream-K seams there), else
+// the rounds at least 60 % full on average.
 inline bool conv_use_wino2d(const W2Geom& q, bool prologue) {
   if (!q.ok || prologue || g_wino2d == 1 || g_wino_mode == 0) return false;
   if (g_wino2d == 2) return true;
   const long rounds = (q.ntl + HPVG_NUM_CU - 1) / HPVG_NUM_CU;
+  if (rounds == 1) return q.ntl * 2 >= HPVG_NUM_CU;
   return (long)q.ntl * 10 >= 6L * rounds * HPVG_NUM_CU;
 }
 template <typename K>
