@@ -1267,6 +1267,9 @@ WPlan plan_wgradw2_search(int B, int Cin, int Cout, int T, int H, int W, int KT)
     if (Tw == prev_tw || (long)(ntw - 1) * Tw >= W) continue;
     prev_tw = Tw;
     const int RSx = Tw + 8;
+    // bands of 4 / 8 columns stage twice their width in halo and lose to wider ones although they pad least (measured at
+    // 5 x 57 x 102: the 10 x 8 tile the area rule picked 0.128 ms, 6 x 16 0.115, 4 x 24 0.105): only where nothing wider fits
+    if (Tw < 12 && W >= 24 && !force) continue;
     for (int Th = 2; Th <= H + 3; Th += 2) {
       const int nth = hpvg_cdiv(H, Th);
       const int thb = 2 * hpvg_cdiv(hpvg_cdiv(H, nth), 2);       // balanced, even
