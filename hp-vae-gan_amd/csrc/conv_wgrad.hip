@@ -1836,6 +1836,18 @@ int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W
   return HPVG_OK;
 }
 
+// host only: the tile plan of the two-axis Winograd weight-gradient kernel (conv_wgradw2_kernel): out[0..9] as
+// hpvg_conv_bwd_weight_plan, out[10] = 1 when this shape runs it by default (the size rule); HPVG_ERR_UNSUPPORTED when no tile fits
+int hpvg_conv_bwd_weight_wino2_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
+  if (!out || (KT != 1 && KT != 3) || B < 1 || Cin < 1 || Cout < 1 || T < 1 || H < 1 || W < 1) return HPVG_ERR_ARG;
+  const WPlan p = plan_wgradw2(B, Cin, Cout, T, H, W, KT);
+  if (p.Th == 0) return HPVG_ERR_UNSUPPORTED;
+  out[0] = p.Th; out[1] = p.Tw; out[2] = p.nth; out[3] = p.ntw; out[4] = p.QK; out[5] = p.S; out[6] = p.DS; out[7] = p.XS;
+  out[8] = (int)p.lds; out[9] = B * T * p.nth * p.ntw;
+  out[10] = wgradw2_wanted(p, B, Cin, Cout, T, H, W, KT) ? 1 : 0;
+  return HPVG_OK;
+}
+
 int hpvg_conv_bwd_weight_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out) {
   if (!out || (KT != 1 && KT != 3)) return HPVG_ERR_ARG;
   const WPlan p = plan_wgrad(B, Cin, Cout, T, H, W, KT);

@@ -48,6 +48,7 @@ _SIGS = {
     "hpvg_conv_bwd_weight_f32": [P, P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_wino_plan": [I, I, I, I, I, I, I, P],
+    "hpvg_conv_bwd_weight_wino2_plan": [I, I, I, I, I, I, I, P],
     "hpvg_conv_bwd_weight_wino_config": [I],
     "hpvg_conv_bwd_weight_fuses_bias": [I, I, I, I, I, I, I],
     "hpvg_conv_bwd_weight_bias_f32": [P, P, P, I, P, I, P, Z, I, I, I, I, I, I, I, P],

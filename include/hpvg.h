@@ -119,6 +119,9 @@ int hpvg_conv_bwd_weight_fuses_bias(int B, int Cin, int Cout, int T, int H, int 
 int hpvg_conv_bwd_weight_bias_f32(const float* dy, const float* x, float* dw, int accumulate, float* db, int accumulate_db, void* ws,
                                   size_t ws_bytes, int B, int Cin, int Cout, int T, int H, int W, int KT, void* stream);
 int hpvg_conv_bwd_weight_wino_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out10); /* host only */
+/* host only: tile plan of the two-axis Winograd weight-gradient kernel: out[0..9] as above, out[10] = 1 when the shape runs it by
+ * default (size rule) */
+int hpvg_conv_bwd_weight_wino2_plan(int B, int Cin, int Cout, int T, int H, int W, int KT, int* out11);
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradient.  accumulate != 0: out[c] += (the caller passes the parameter's
  * gradient buffer, which removes autograd's AccumulateGrad add kernel) */
 size_t hpvg_channel_sum_ws_bytes(int C);

@@ -121,6 +121,40 @@ def test_winograd_weight_gradient_plan_geometry():
         lib.hpvg_conv_bwd_weight_wino_config(prev)
 
 
+def test_two_axis_weight_gradient_plan_geometry():
+    """The tile plan of conv_wgradw2_kernel over every width 1 .. 300 (the kernel takes any: odd widths and W % 4 != 0 through
+    the straddle patch): an even tile height, bands of a multiple of 4 columns (never 4 / 8 wide where a wider band fits), an
+    even number of K steps (Th * Tw % 16 = 0: the loop body holds two), at most two 64-lane pieces per channel row and operand,
+    channel strides 2 (mod 4), every read of the K loop inside its channel row, two buffers in LDS, and the straddling group of
+    a W % 4 != 0 row inside the band that stages it."""
+    lib = hplib.load()
+    out = (ctypes.c_int * 11)()
+    for KT, T in ((3, 5), (1, 1)):
+        for H in (1, 2, 9, 45, 91, 144):
+            for W in range(1, 301):
+                assert lib.hpvg_conv_bwd_weight_wino2_plan(2, 64, 64, T, H, W, KT, out) == 0, (KT, H, W)
+                Th, Tw, nth, ntw, QK, S, DS, XS, lds, ntiles, wanted = list(out)
+                assert Th % 2 == 0 and Tw % 4 == 0 and QK == Th * Tw and QK % 16 == 0
+                assert ntw * Tw >= W and (ntw - 1) * Tw < W and nth * Th >= H and (nth - 1) * Th < H + 3
+                assert Tw >= 12 or W < 24, (H, W, Tw)
+                RS = Tw + 8
+                assert DS == QK + 2 and XS == (Th + 2) * RS + 2 and DS % 4 == 2 and XS % 4 == 2
+                assert Th * (Tw // 4) <= 128 and (Th + 2) * (Tw // 4 + 2) <= 128
+                assert lds == 2 * 64 * (DS + XS) * 4 and lds <= 160 * 1024
+                # furthest reads of a step: dY row 1 of the last quad row, X patch row 3 / column pair 1 of the last quad
+                assert (Th - 1) * Tw + (Tw - 2) + 1 < DS and (Th + 1) * RS + (Tw - 2) + 4 + 3 < XS
+                assert ntiles == 2 * T * nth * ntw and 1 <= S <= 256 and wanted in (0, 1)
+                if W % 4:
+                    gs = W - W % 4                      # the straddling group lies in the last band's dY rows and X rows
+                    w0 = (ntw - 1) * Tw
+                    assert 0 <= gs - w0 < Tw and 0 <= gs - (w0 - 4) < Tw + 8
+                assert hplib.call("hpvg_conv_bwd_weight_ws_bytes", 2, 64, 64, T, H, W, KT) >= 256 + S * KT * 16 * 4096 * 4
+    # the size rule: the stage shapes of the video pyramid that run it by default (B = 2)
+    for (T, H, W), want in {(13, 144, 256): 1, (7, 114, 204): 1, (7, 91, 162): 1, (7, 72, 129): 1, (5, 57, 102): 1, (5, 36, 65): 1,
+                            (4, 18, 33): 0}.items():
+        assert lib.hpvg_conv_bwd_weight_wino2_plan(2, 64, 64, T, H, W, 3, out) == 0 and out[10] == want, (T, H, W, out[10])
+
+
 def test_tables_match_reference():
     rows = json.load(open(os.path.join(GOLDEN, "tables.json")))
     for row in rows:
