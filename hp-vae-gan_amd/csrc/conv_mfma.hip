@@ -30,6 +30,9 @@ namespace {
 
 // source of zero padding for the LDS-DMA staging (out-of-image lanes read this word)
 __device__ const float g_zero_word[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// a whole H x W plane of zeros (conv_wino2r_kernel: a time plane outside the clip is staged like any other, from here)
+constexpr long HPVG_ZERO_PLANE_FLOATS = 1L << 18;
+__device__ float g_zero_plane[HPVG_ZERO_PLANE_FLOATS];
 
 #ifdef HPVG_TRACE
 // development build only (tools/trace_conv.py): per-workgroup start/end (100 MHz clock) and placement
@@ -201,6 +204,26 @@ __device__ __forceinline__ void conv_dma_piece16(const char* base_, unsigned vof
       : "=&s"(keep_exec), "=&s"(keep_m0)
       : "v"(voff), "s"(mask), "s"(lds_addr), "s"(base)
       : "memory");
+}
+
+// The 16-byte piece for call sites where EVERY lane of the wave is active (the K loops): EXEC goes back to all ones by
+// constant and m0 is declared clobbered instead of saved and restored - measured with tools/mfma_fillers.hip, a vector-memory
+// instruction between two fp32 MFMAs costs the matrix pipe ~40 cycles whatever its width or its active lanes, and the
+// save / restore pairs another 16 (the restoring s_mov of m0 and of exec each delay the MFMA behind them); this form: 47.
+__device__ __forceinline__ void conv_dma_piece16_all(const char* base_, unsigned voff, unsigned lds_addr, unsigned long long mask) {
+  const unsigned long long bb = (unsigned long long)base_;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bb);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bb >> 32));
+  const unsigned long long base = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  asm volatile(
+      "s_mov_b64 exec, %1\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %3\n\t"
+      "s_mov_b64 exec, -1"
+      :
+      : "v"(voff), "s"(mask), "s"(lds_addr), "s"(base)
+      : "memory", "m0");
 }
 
 // Stage channel chunk `ch` (CC channels x KT time planes) of the tile of sample b / output plane t into xs.
@@ -1278,6 +1301,7 @@ struct W2Geom { int Cq, R, ntq, tqw, gridy, nsc, ntl; bool ok; };
 inline W2Geom wino2d_geom(int B, int Cin, int Cout, int T, int H, int W, int KT) {
   W2Geom q{};
   if (!conv_is_wino2d(Cin, Cout, KT) || ((W & 1) && !g_wino2r) || W < 2 || (long)H * W < 4) return q;   // (odd W: conv_wino2r_kernel's ODD instance)
+  if (g_wino2r && (long)H * W + 4 > HPVG_ZERO_PLANE_FLOATS) return q;                                     // (its zero plane)
   q.Cq = (W + 1) / 2;
   q.R = hpvg_cdiv(H, 2);
   const int nq = q.R * q.Cq;

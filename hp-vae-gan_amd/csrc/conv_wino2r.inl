@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
   const int nsc = a.nsc;
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)xs;
   const char* zero_ptr = reinterpret_cast<const char*>(g_zero_word);
+  const char* zero_plane = reinterpret_cast<const char*>(g_zero_plane);
 
   // U-fragment stream: [sc][step = dt*2 + cp][row i][m-tile] fragments of 64 lanes x 16 bytes (the four points of a row)
   const long afrag = (long)a.mbtot * 64 * 16;        // bytes between two rows' fragments
@@ -322,9 +323,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       const unsigned xb[2] = {cbb + (unsigned)rd_cur.bb[0] * 4u, cbb + (unsigned)rd_cur.bb[1] * 4u};
       const unsigned xan[2] = {nbb + (unsigned)(wrap ? rd_nxt.ba[0] : rd_cur.ba[0]) * 4u, nbb + (unsigned)(wrap ? rd_nxt.ba[1] : rd_cur.ba[1]) * 4u};
       const unsigned xbn[2] = {nbb + (unsigned)(wrap ? rd_nxt.bb[0] : rd_cur.bb[0]) * 4u, nbb + (unsigned)(wrap ? rd_nxt.bb[1] : rd_cur.bb[1]) * 4u};
-      // plane pl = cc * 3 + dt of the next item into buffer nb: a valid plane comes through its scalar base + this lane's
-      // tile-constant byte offset under the tile's EXEC mask (no vector instruction at all: the fp32 MFMA shares the vector ALU),
-      // a plane outside the clip / past Cin from the zero word (every lane)
+      // plane pl = cc * 3 + dt of the next item into buffer nb: through a scalar base + this lane's tile-constant byte offset
+      // under the tile's EXEC mask (no vector instruction at all: the fp32 MFMA shares the vector ALU); a plane outside the clip /
+      // past Cin reads g_zero_plane with the same offsets and mask - ONE straight-line piece per plane, the source a scalar
+      // select (with a branch to a second piece that read the zero word the stage-9 launch ran 3 % longer)
       const char* pl_base = wrap ? plane0(st_nxt, 0) : plane0(st_cur, 0) + (long)nsc_i * scstride;
       const unsigned n_voff = wrap ? st_nxt.voff : st_cur.voff;
       const unsigned long long n_okm = wrap ? st_nxt.okm : st_cur.okm;
@@ -333,8 +335,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
   {                                                                                                               \
     const int cc_ = (PLN) / 3, dt_ = (PLN) - 3 * cc_;                                                             \
     const bool pok_ = nch0 + cc_ < a.Cin && n_t + dt_ - 1 >= 0 && n_t + dt_ - 1 < a.T;                            \
-    if (pok_) conv_dma_piece16(pl_base + ((long)cc_ * THWb + (long)dt_ * HWb), n_voff, ldsn + (unsigned)((PLN) * PL * 4), n_okm); \
-    else conv_dma_piece16(zero_ptr, vzero, ldsn + (unsigned)((PLN) * PL * 4), ~0ull);                             \
+    const char* src_ = pok_ ? pl_base + ((long)cc_ * THWb + (long)dt_ * HWb) : zero_plane;                        \
+    conv_dma_piece16_all(src_, n_voff, ldsn + (unsigned)((PLN) * PL * 4), n_okm);                                 \
   }
       // ---- wait counts (vector-memory ops return in order).  Per item this wave issues, in program order: step s < 3: four
       // DMA pieces (slots 1, 5, 9, 13), then the two U loads of ring slot s for the NEXT item (slots 14, 15); steps 3-5: the
