@@ -361,7 +361,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     if ((K) >= 6 && (K) < 10) WG2_XH(((K) - 6) & 3, v03##N, v12##N)                                                      \
     if ((K) == 11) WG2_YXF(ry##N, rv1##N, rv2##N, y12##N)                                                          \
     if (((K) & 3) == 1 && ((K) >> 2) < PS) WG2_DMA(((SP) * PS + ((K) >> 2)) % NP)                                  \
+    WG2_PIN                                                                                                        \
   }
+// (the slots are pinned: left to itself hipcc gathers the vector work of a step behind its first MFMAs, where the LDS reads
+// issued in slot 0 have not landed yet - stage 9 -2.4 %, stage 8 -5 %)
+#define WG2_PIN __builtin_amdgcn_sched_barrier(0);
 #define WG2_STEP(SP, C, N)                                                                                         \
   {                                                                                                                \
     WG2_SLOT(SP, 0, C, N) WG2_SLOT(SP, 1, C, N) WG2_SLOT(SP, 2, C, N) WG2_SLOT(SP, 3, C, N)                        \
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
         WG2_STEP(1, B, A)
       }
 #undef WG2_STEP
+#undef WG2_PIN
 #undef WG2_SLOT
 #undef WG2_VOP
 #undef WG2_YOP

@@ -12,7 +12,7 @@ import csv
 rows=list(csv.DictReader(open("$O/stage${st}_kernel_stats.csv")))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 print("total %.2f ms over 4 iterations" % (tot/1e6))
-for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:16]:
+for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:28]:
     print("%5.1f%%  calls %5s avg %8.1f us  %s" % (100*float(r["TotalDurationNs"])/tot, r["Calls"], float(r["AverageNs"])/1e3, r["Name"].replace("(anonymous namespace)::","")[:90]))
 PY
 done
