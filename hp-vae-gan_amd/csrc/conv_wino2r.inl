@@ -395,6 +395,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
     // front of step 5, whose LDS reads are the next buffer's) nor the third buffer (the item before), and no DMA targets
     // either before the next item starts.  Region (sender v, destination block d != v) = 8 x 64 lanes x 16 bytes, six regions
     // per buffer; write k of a region holds (s0, s1) of the accumulator elements 2k and 2k + 1.
+#ifdef HPVG_ABL2_NOEPI   // (development ablation, timing only: no exchange, no output transform, no stores)
+    if (a.nsc == -12345) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a.y[(q * 16 + e) * 256 + tid] = acc[q][e];
+    }
+    if (false)
+#endif
     {
       const int third = bufsel == 2 ? 0 : bufsel + 1;       // (bufsel = the next item's buffer)
       // ---- what the epilogue of the owned block (m-tile mw, quad half nw) loads is issued first: its latency passes behind
@@ -513,6 +522,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #pragma unroll
           for (int p = 0; p < 4; ++p) yv[p] *= ((mwd[p] >> shb) & 1u) ? 1.f : HPVG_LRELU_SLOPE;
         }
+#ifdef HPVG_ABL2_NOSTORE   // (development ablation, timing only: the epilogue without its output stores)
+        if (a.nsc == -12345)
+#endif
         if (!ODD || c_w + 1 < W) {
           if (cok && r0ok) {
             f32x2u4 o2;
