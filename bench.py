@@ -283,7 +283,7 @@ def roofline_family(g, KT):
 
 CONV_KIND = {0: ("conv_mfma_kernel + conv_fixup_kernel (direct implicit GEMM, stream-K)", 1.0),
              1: ("conv_wino_kernel + conv_wino_fixup_kernel (Winograd F(2,3) along W, stream-K)", 2.0 / 3.0),
-             2: ("conv_wino2d_kernel (Winograd F(2x2,3x3) over H and W, one software-pipelined workgroup per CU)", 4.0 / 9.0),
+             2: ("conv_wino2r_kernel (Winograd F(2x2,3x3) over H and W, one software-pipelined workgroup per CU, a point row per wave)", 4.0 / 9.0),
              3: ("conv_narrow2_kernel (narrow output: taps in the GEMM N axis)", 1.0)}
 WGRAD_KIND = {0: ("conv_wgrad_kernel + conv_wgrad_reduce_kernel (direct, a workgroup per time tap)", 1.0),
               1: ("conv_wgrad3_kernel + conv_wgrad3_reduce_kernel (direct, all taps per workgroup)", 1.0),
