@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       const float* dl = bufc + (oblk * 32 + l31) * DS + 2 * half;
       const float* xl = bufc + 64 * DS + (cblk * 32 + l31) * XS + 2 * half + 4;
       int dyo = 0, xo = 0, wc = 0, ls = 0;   // offsets of the step being LOADED (steps are loaded in order, then wrap)
+      // this lane's addresses of that step, made in the step's vector slot (WG2_ADDR: not a lone vector add beside the reads)
+      // (32-bit LDS addresses: a generic pointer laundered through an asm statement loses its address space - flat loads)
+      typedef __attribute__((address_space(3))) const wf32x2a* wg2_lp;
+      const unsigned dl0 = (unsigned)(size_t)(lptr_t)const_cast<float*>(dl), xl0 = (unsigned)(size_t)(lptr_t)const_cast<float*>(xl);
+      unsigned dlp = dl0, xlp = xl0;
+#define WG2_ADDR() { dlp = dl0 + 4u * (unsigned)dyo; xlp = xl0 + 4u * (unsigned)xo; asm volatile("" : "+v"(dlp), "+v"(xlp)); }
       wf32x2a rx[4][2] = {};                  // raw input patch of the next step: rx[row][pair]
       // per register set: the dY quad rows ry[0..1] (also points (0, 0/3) and (3, 0/3)), their sum / difference rv1, rv2 (rows
       // 1, 2: points (i, 0/3)), y12[i] = points (i, 1), (i, 2); v03[i] = points (i, 0), (i, 3), v12[i] = (i, 1), (i, 2)
@@ -280,11 +286,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 #else
 #define WG2_LOAD(RY)                                                                        \
   {                                                                                         \
-    RY[0] = *reinterpret_cast<const wf32x2a*>(dl + dyo);                                    \
-    RY[1] = *reinterpret_cast<const wf32x2a*>(dl + dyo + TwR);                              \
+    RY[0] = *(wg2_lp)(size_t)(dlp);                                                         \
+    RY[1] = *(wg2_lp)(size_t)(dlp + 4u * (unsigned)TwR);                                    \
     _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                      \
-      rx[r_][0] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RSR);                    \
-      rx[r_][1] = *reinterpret_cast<const wf32x2a*>(xl + xo + r_ * RSR + 2);                \
+      rx[r_][0] = *(wg2_lp)(size_t)(xlp + 4u * (unsigned)(r_ * RSR));                       \
+      rx[r_][1] = *(wg2_lp)(size_t)(xlp + 4u * (unsigned)(r_ * RSR + 2));                   \
     }                                                                                       \
     dyo += 4;                                                                               \
     xo += 4;                                                                                \
@@ -355,17 +361,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 #define WG2_SLOT(SP, K, C, N)                                                                                      \
   {                                                                                                                \
     acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(WG2_YOP(K, ry##C, rv1##C, rv2##C, y12##C), WG2_VOP(K, v03##C, v12##C), acc[K], 0, 0, 0); \
-    if ((K) == 0) bsum = __builtin_fmaf(bflag, y12##C[1][0], bsum);                                                \
     if ((K) == 0) WG2_LOAD(ry##N)                                                                                  \
-    if ((K) == 4) WG2_XV()                                                                                         \
-    if ((K) >= 6 && (K) < 10) WG2_XH(((K) - 6) & 3, v03##N, v12##N)                                                      \
-    if ((K) == 11) WG2_YXF(ry##N, rv1##N, rv2##N, y12##N)                                                          \
+    WG2_XF_SLOTS(K, C, N)                                                                                          \
     if (((K) & 3) == 1 && ((K) >> 2) < PS) WG2_DMA(((SP) * PS + ((K) >> 2)) % NP)                                  \
     WG2_PIN                                                                                                        \
   }
 // (the slots are pinned: left to itself hipcc gathers the vector work of a step behind its first MFMAs, where the LDS reads
 // issued in slot 0 have not landed yet - stage 9 -2.4 %, stage 8 -5 %)
 #define WG2_PIN __builtin_amdgcn_sched_barrier(0);
+// the whole vector work of a step in ONE slot (after the LDS reads of slot 0 have had four MFMAs to land): beside fp32 MFMAs a
+// group of vector instructions costs ~10 cycles + ~4.5 per instruction (tools/mfma_fillers.hip: 4 per gap +29 cycles, 8: +45,
+// 16: +82; a lone one +14) - spread over seven slots the step paid that fixed part seven times (-1 %)
+#define WG2_XF_SLOTS(K, C, N)                                                                                      \
+    if ((K) == 4) { WG2_XV() WG2_XH(0, v03##N, v12##N) WG2_XH(1, v03##N, v12##N) WG2_XH(2, v03##N, v12##N) WG2_XH(3, v03##N, v12##N) \
+                    WG2_YXF(ry##N, rv1##N, rv2##N, y12##N)                                                         \
+                    bsum = __builtin_fmaf(bflag, y12##C[1][0], bsum);                                              \
+                    WG2_ADDR() }
 #define WG2_STEP(SP, C, N)                                                                                         \
   {                                                                                                                \
     WG2_SLOT(SP, 0, C, N) WG2_SLOT(SP, 1, C, N) WG2_SLOT(SP, 2, C, N) WG2_SLOT(SP, 3, C, N)                        \
@@ -379,11 +390,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
       // the tile's first step: in-bounds reads whose results are dropped).
       WG2_LOAD(ryA)
       WG2_TRANSFORM(ryA, rv1A, rv2A, y12A, v03A, v12A)
+      WG2_ADDR()
       for (int st = 0; st < nsteps; st += 2) {
         WG2_STEP(0, A, B)
         WG2_STEP(1, B, A)
       }
 #undef WG2_STEP
+#undef WG2_ADDR
+#undef WG2_XF_SLOTS
 #undef WG2_PIN
 #undef WG2_SLOT
 #undef WG2_VOP
