@@ -346,23 +346,30 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
       // Before step 5 the next buffer must be complete: younger than the last piece (step 2, slot 13) are the U loads of
       // steps 2, 3, 4 -> vmcnt(6), then the barrier.  The kernel ends with vmcnt(0).
       // ---- one step = 16 slots of one MFMA each (K = (m-tile * 2 + quad half) * 4 + j) plus: slot 0 the LDS reads of the next
-      // step's rows, 4-7 its vertical pass, 8-11 its horizontal pass, 1 / 5 / 9 / 13 a DMA piece (steps 0-2; address one slot
-      // earlier), 14-15 the U loads.  Steps alternate between the operand sets vA / vB (no copies); step 5 prepares step 0 of
+      // step's rows, 4 its transform (vertical + horizontal pass: one group of vector instructions), 1 / 5 / 9 / 13 a DMA piece
+      // (steps 0-2), 14-15 the U loads.  Steps alternate between the operand sets vA / vB (no copies); step 5 prepares step 0 of
       // the NEXT item (buffer nb, the next tile's geometry at a tile wrap).
 #define W2R_SLOT(STEP, K, VC, VN)                                                                                  \
   {                                                                                                                \
     acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[STEP][(K) >> 3][(K) & 3], VC[((K) >> 2) & 1][(K) & 3], acc[K], 0, 0, 0); \
     if ((K) == 0 && (STEP) < 5) W2R_LOAD_RAW(xa, xb, (STEP) + 1)                                                   \
     if ((K) == 0 && (STEP) == 5) W2R_LOAD_RAW(xan, xbn, 0)                                                         \
-    if ((K) == 4) W2R_WAIT_RAW();                                                                                  \
-    if ((K) >= 4 && (K) < 8) W2R_VERT((((K) - 4) >> 1) & 1, (K) & 1)                                                     \
-    if ((K) >= 8 && (K) < 12 && (STEP) < 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, f0, f3, f2)                          \
-    if ((K) >= 8 && (K) < 12 && (STEP) == 5) W2R_HORZ((((K) - 8) >> 1) & 1, (K) & 1, VN, nf0, nf3, nf2)                       \
+    W2R_XF_SLOTS(STEP, K, VN)                                                                                      \
     if (((K) & 3) == 0 && (STEP) < 3) W2R_STAGE_ADDR((STEP) * 4 + ((K) >> 2))                                      \
     if (((K) & 3) == 1 && (STEP) < 3) W2R_ABL_STAGE((STEP) * 4 + ((K) >> 2))                                       \
     if ((K) >= 14) W2R_ABL_LOADA(au[STEP][(K) & 1], aoff, anext + (long)((STEP) * 4) * afrag + ((K) & 1) * 1024);  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
   }
+// the transform of the next step's patches as ONE group in slot 4 (the LDS reads of slot 0 have had four MFMAs to land): beside
+// fp32 MFMAs a group of vector instructions costs ~10 cycles + ~4.5 per instruction (tools/mfma_fillers.hip: 4 per gap +29
+// cycles, 8: +45, 16: +82; a lone one +14) - spread over slots 4-11 the step paid the fixed part eight times: stage 9 -3.1 %
+#define W2R_XF_SLOTS(STEP, K, VN)                                                                                  \
+    if ((K) == 4) {                                                                                                \
+      W2R_WAIT_RAW();                                                                                              \
+      W2R_VERT(0, 0) W2R_VERT(0, 1) W2R_VERT(1, 0) W2R_VERT(1, 1)                                                  \
+      if ((STEP) < 5) { W2R_HORZ(0, 0, VN, f0, f3, f2) W2R_HORZ(0, 1, VN, f0, f3, f2) W2R_HORZ(1, 0, VN, f0, f3, f2) W2R_HORZ(1, 1, VN, f0, f3, f2) } \
+      else { W2R_HORZ(0, 0, VN, nf0, nf3, nf2) W2R_HORZ(0, 1, VN, nf0, nf3, nf2) W2R_HORZ(1, 0, VN, nf0, nf3, nf2) W2R_HORZ(1, 1, VN, nf0, nf3, nf2) } \
+    }
 #define W2R_STEP(STEP, NWAIT, VC, VN)                                                                              \
   {                                                                                                                \
     W2R_WAIT_A(NWAIT, STEP);                                                                                       \
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #endif
       W2R_STEP(5, 22, vB, vA)
 #undef W2R_STEP
+#undef W2R_XF_SLOTS
 #undef W2R_SLOT
 #undef W2R_STAGE
 #undef W2R_STAGE_ADDR
