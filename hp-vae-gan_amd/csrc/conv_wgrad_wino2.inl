@@ -125,9 +125,23 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
   bool st_tok = false;      // the staged tile's input plane lies inside the clip (= it has work for this time tap)
   const float* pt_dyb = nullptr;
   const float* pt_xb = nullptr;
-  auto setup = [&](int tile) {
-    int b, t, th_i, tw_i;
-    decode(tile, b, t, th_i, tw_i);
+  // this lane's group of piece j inside the tile: row (<< 16) | column offset + 8 - the same for every tile, and a division by a
+  // run-time group count per piece: hoisted out of the tile loop (the set-up of a tile is not hidden behind anything: one wave
+  // per SIMD)
+  int dgrp[NJD], xgrp[NJX];
+#pragma unroll
+  for (int j = 0; j < NJD; ++j) {
+    const int p = j * LW + lane;
+    const int hh = p / gpr;
+    dgrp[j] = (hh << 16) | (4 * (p - hh * gpr) + 8);
+  }
+#pragma unroll
+  for (int j = 0; j < NJX; ++j) {
+    const int p = j * LW + lane;
+    const int hh = p / gprx;
+    xgrp[j] = (hh << 16) | (4 * (p - hh * gprx) - 3 + 8);
+  }
+  auto setup = [&](int b, int t, int th_i, int tw_i) {
     const int tt = t + dt - pt;
     const bool tok = tt >= 0 && tt < a.T;
     st_tok = tok;
@@ -143,8 +157,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     }
 #pragma unroll
     for (int j = 0; j < NJD; ++j) {
-      const int p = j * LW + lane;
-      const int hh = p / gpr, ww = 4 * (p - hh * gpr);
+      const int hh = dgrp[j] >> 16, ww = (dgrp[j] & 0xffff) - 8;
       const int gh = h0 + hh, gw = w0 + ww;
       const bool ok = hh < a.Th && gh < a.H && gw + (STRAD ? 3 : 0) < a.W;   // (a group is loaded when it lies wholly inside the row)
       dptr[j] = ok ? (const char*)(dyb + gh * a.W + gw) : (const char*)g_wzero;
@@ -152,8 +165,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     }
 #pragma unroll
     for (int j = 0; j < NJX; ++j) {
-      const int p = j * LW + lane;
-      const int hh = p / gprx, ww = 4 * (p - hh * gprx) - 3;
+      const int hh = xgrp[j] >> 16, ww = (xgrp[j] & 0xffff) - 8;
       const int gh = h0 + hh - 1, gw = w0 + ww - 1;
       const bool ok = tok && hh < a.Th + 2 && gh >= 0 && gh < a.H && gw >= 0 && gw + (STRAD ? 3 : 0) < a.W;
       xptr[j] = ok ? (const char*)(xb + gh * a.W + gw) : (const char*)g_wzero;
@@ -226,8 +238,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
 
   int tile = slot;
   __syncthreads();  // zero fill done
+  // the tile's coordinates (sample, plane, band row, band column) move on by the decoded step `nslot` with carries instead of
+  // three divisions per tile (order 1: the column runs fastest; order 0: the plane)
+  int cb_ = 0, ct_ = 0, ch_ = 0, cw_ = 0, sb_ = 0, st_ = 0, sh_ = 0, sw_ = 0;
+  decode(tile < ntiles ? tile : 0, cb_, ct_, ch_, cw_);
+  decode(nslot, sb_, st_, sh_, sw_);
+  auto advance = [&]() __attribute__((always_inline)) {
+    if (a.order == 0) {
+      ct_ += st_; int c = ct_ >= a.T ? 1 : 0; ct_ -= c ? a.T : 0;
+      cw_ += sw_ + c; c = cw_ >= a.ntw ? 1 : 0; cw_ -= c ? a.ntw : 0;
+      ch_ += sh_ + c; c = ch_ >= a.nth ? 1 : 0; ch_ -= c ? a.nth : 0;
+      cb_ += sb_ + c;
+    } else {
+      cw_ += sw_; int c = cw_ >= a.ntw ? 1 : 0; cw_ -= c ? a.ntw : 0;
+      ch_ += sh_ + c; c = ch_ >= a.nth ? 1 : 0; ch_ -= c ? a.nth : 0;
+      ct_ += st_ + c; c = ct_ >= a.T ? 1 : 0; ct_ -= c ? a.T : 0;
+      cb_ += sb_ + c;
+    }
+  };
   if (tile < ntiles) {
-    setup(tile);
+    setup(cb_, ct_, ch_, cw_);
     dma_begin(lds);
     cnext = 0;
     while (cnext < NCH) dma_channel();
@@ -245,9 +275,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradw2_kernel(const WgradArgs a)
     cnext = NCH;
     if (have_next) {
 #ifdef HPVG_ABLW2_NOSETUP   // (development ablation, timing only: every tile stages the first one again, the set-up hoisted)
-      setup(slot);
+      { int b0_, t0_, h0_, w0_; decode(slot, b0_, t0_, h0_, w0_); setup(b0_, t0_, h0_, w0_); }
 #else
-      setup(next);
+      advance();
+      setup(cb_, ct_, ch_, cw_);
 #endif
       dma_begin(lds + (cur ^ 1) * BUF);
       cnext = 0;
