@@ -411,3 +411,18 @@ def test_graph_capture_refusal_restores_host_state(monkeypatch):
     assert trainer.iteration == 6 and [m.pending_batches for m in net] == [11, 11]          # warm-up counted, recording undone
     assert trainer._graph is not None and trainer._g_out == {"loss": 1.0}
     assert [(m.pending_batches, d) for m, d in trainer._graph_bn] == [(11, 2), (11, 2)]    # what every replay adds
+
+
+def test_two_axis_conv_is_bounded_by_its_zero_plane_and_offsets():
+    """conv_wino2r_kernel stages a time plane outside the clip from a device plane of zeros (2^18 floats) and addresses its
+    epilogue with 32-bit offsets: the size rule (host only) must hand larger planes / volumes to the one-axis kernel (kind 1)
+    and keep the pyramid's big shapes on the two-axis kernel (kind 2)."""
+    lib = hplib.load()
+    kind = lib.hpvg_conv_fwd_kernel_kind
+    assert kind(2, 64, 64, 13, 144, 256, 3) == 2          # stage 9 of the BASELINE video config
+    assert kind(2, 64, 64, 7, 114, 204, 3) == 2           # stage 8
+    assert kind(2, 64, 64, 5, 1000, 256, 3) == 2          # a plane of 256 000 floats: below the zero plane's 2^18
+    assert kind(2, 64, 64, 5, 1024, 256, 3) != 2          # 2^18 floats + the 4 the check keeps free: too large
+    assert kind(2, 64, 64, 5, 1100, 256, 3) != 2
+    assert kind(2, 64, 64, 5, 512, 512, 3) != 2           # (a tile's staged span must fit 1024 floats: W <= 256 for half-row tiles)
+    assert kind(2, 64, 64, 13, 144, 256, 1) != 2          # the 2-D convs never run it
