@@ -181,6 +181,9 @@ def test_conv_winograd_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B
     # H * W = 1, 3 (mod 4) (the plane-end patch copies 1 or 3 floats) and even H, several tiles per plane, W = 3, ragged channels
     (1, 64, 64, (2, 5, 7)), (2, 64, 64, (3, 36, 65)), (1, 64, 64, (2, 9, 129)), (1, 24, 40, (2, 3, 3)), (1, 64, 64, (3, 7, 5)),
     (2, 64, 64, (2, 5, 9)), (1, 64, 64, (4, 18, 33)),
+    # a tall plane (256 000 floats: just below the kernel's zero plane of 2^18): the time planes outside the clip are staged from
+    # that zero plane with the tile's own lane offsets - up to 1 MB into it
+    (1, 8, 40, (2, 1000, 256)),
 ])
 def test_conv_winograd_two_axis_kernel_against_direct_kernel_and_oracle(ops, wino_mode, B, Cin, Cout, sp):
     """conv_wino2d_kernel (F(2x2, 3x3) over H and W, one workgroup per CU, software-pipelined with hand-counted waits;
