@@ -223,25 +223,43 @@ __global__ __launch_bounds__(256, 1) void conv_wino2r_kernel(const Wino2Args a) 
 #define W2R_RA(QH, C) (ODD ? rfa[QH][C] : rwa[QH][(C) >> 1][(C) & 1])
 #define W2R_RB(QH, C) (ODD ? rfb[QH][C] : rwb[QH][(C) >> 1][(C) & 1])
 // vertical pass of row ri, columns 2 P, 2 P + 1 of quad half QH
+// (even W: on the 8-byte pairs as they come from LDS - one packed fma per pair: beside the MFMAs a packed instruction costs
+// ~5.3 cycles against 2 x 4.5)
 #define W2R_VERT(QH, P)                                                                         \
   {                                                                                             \
-    tn[QH][2 * (P)] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P)), W2R_RA(QH, 2 * (P)));             \
-    tn[QH][2 * (P) + 1] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P) + 1), W2R_RA(QH, 2 * (P) + 1)); \
+    if constexpr (!ODD) {                                                                       \
+      asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tp[QH][P]) : "v"(sv2), "v"(rwb[QH][P]), "v"(rwa[QH][P])); \
+      tn[QH][2 * (P)] = tp[QH][P][0];                                                           \
+      tn[QH][2 * (P) + 1] = tp[QH][P][1];                                                       \
+    } else {                                                                                    \
+      tn[QH][2 * (P)] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P)), W2R_RA(QH, 2 * (P)));           \
+      tn[QH][2 * (P) + 1] = __builtin_fmaf(sv, W2R_RB(QH, 2 * (P) + 1), W2R_RA(QH, 2 * (P) + 1)); \
+    }                                                                                           \
   }
 // horizontal pass: points (ri, 0), (ri, 1) (P = 0) or (ri, 2), (ri, 3) (P = 1) with the image-border factors folded in
 // (ODD: column 2 of the patch may lie outside the image as well: t2 is scaled by f2 first)
+// (even W: the two middle points (t1 + t2, t2 - t1) as ONE packed add on the pairs (t0, t1), (t2, t3): both lanes take t2 from
+// the second pair's low half, t1 from the first pair's high half, negated in the high lane)
 #define W2R_HORZ(QH, P, OUT, F0, F3, F2)                                                        \
   {                                                                                             \
     if ((P) == 0) {                                                                             \
       if constexpr (ODD) tn[QH][2] *= F2[QH];                                                   \
       OUT[QH][0] = __builtin_fmaf(F0[QH], tn[QH][0], -tn[QH][2]);                               \
-      OUT[QH][1] = tn[QH][1] + tn[QH][2];                                                       \
+      if constexpr (ODD) OUT[QH][1] = tn[QH][1] + tn[QH][2];                                    \
     } else {                                                                                    \
-      OUT[QH][2] = tn[QH][2] - tn[QH][1];                                                       \
+      if constexpr (ODD) OUT[QH][2] = tn[QH][2] - tn[QH][1];                                    \
+      else {                                                                                    \
+        f32x2a m2_;                                                                             \
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(m2_) : "v"(tp[QH][1]), "v"(tp[QH][0])); \
+        OUT[QH][1] = m2_[0];                                                                    \
+        OUT[QH][2] = m2_[1];                                                                    \
+      }                                                                                         \
       OUT[QH][3] = __builtin_fmaf(-(F3[QH]), tn[QH][3], tn[QH][1]);                             \
     }                                                                                           \
   }
   f32x2a rwa[2][2], rwb[2][2];
+  const f32x2a sv2 = {sv, sv};
+  f32x2a tp[2][2];                                  // (even W: the vertical pass as pairs (t0, t1), (t2, t3))
   float rfa[2][4], rfb[2][4];                       // (ODD: the rows as four dwords)
   float vA[2][4], vB[2][4], tn[2][4];
 
