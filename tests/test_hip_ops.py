@@ -909,3 +909,36 @@ def test_wgrad_all_taps_kernel_on_small_shapes():
     r = subprocess.run([sys.executable, os.path.join(here, "wgrad3_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "wgrad3 ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_axis_weight_gradient_time_major_tile_walk():
+    """conv_wgradw2_kernel walks its tiles plane-major by default; HPVG_WG2_ORDER=0 (read once per process) selects the time-major
+    walk, whose tile coordinates advance with another carry chain.  A child process with that switch: several tiles per
+    workgroup in every direction (bands x band rows x planes x samples), against the direct kernel."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import hp_vae_gan_amd
+from hp_vae_gan_amd import ops, lib as hplib
+lib = hplib.load()
+torch.manual_seed(5)
+for B, C, sp in ((2, 64, (9, 40, 70)), (3, 64, (5, 33, 52)), (2, 64, (48, 160))):
+    x = torch.randn(B, C, *sp, device="cuda"); dy = torch.randn(B, C, *sp, device="cuda")
+    ws = (C, C) + (3,) * len(sp)
+    out = {}
+    for mode in (0, 5):
+        lib.hpvg_conv_bwd_weight_wino_config(mode)
+        out[mode] = ops.conv_bwd_weight_raw(dy, x, ws)
+    err = float((out[5] - out[0]).abs().max() / out[0].abs().max())
+    kind = lib.hpvg_conv_bwd_weight_kernel_kind(B, C, C, sp[0] if len(sp) == 3 else 1, sp[-2], sp[-1], 3 if len(sp) == 3 else 1)
+    print("shape", B, sp, "kind", kind, "rel err", err)
+    assert kind == 3 and err < 2e-5, (B, sp, kind, err)
+print("time-major ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPVG_WG2_ORDER="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "time-major ok" in r.stdout, r.stdout + r.stderr
