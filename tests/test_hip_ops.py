@@ -942,3 +942,49 @@ print("time-major ok")
     env = dict(os.environ, HPVG_WG2_ORDER="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "time-major ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_first_generation_two_axis_conv_kernel_still_matches():
+    """HPVG_WINO2R=0 (read once per process) puts the two-axis convs back on round 2's conv_wino2d_kernel (every wave transforms
+    whole patches; even widths only), which shares the weight fragments, the epilogue's position-major 1-bit mask words and the
+    launch code with conv_wino2r_kernel.  A child process with that switch: forward, LeakyReLU + bit words, bit-masked and
+    float-masked backward-data against the direct kernel."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import hp_vae_gan_amd
+from hp_vae_gan_amd import ops, lib as hplib
+lib = hplib.load()
+torch.manual_seed(6)
+for B, Cin, Cout, sp in ((2, 64, 64, (3, 36, 64)), (1, 24, 70, (2, 9, 130)), (1, 64, 64, (5, 57, 102))):
+    x = torch.randn(B, Cin, *sp, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Cout, device="cuda"); gy = torch.randn(B, Cout, *sp, device="cuda")
+    res = {}
+    for mode in (5, 0):
+        lib.hpvg_conv_wino_config(mode, -1)
+        y = ops.conv_fwd_raw(x, w, b)
+        ya, bits = ops.conv_fwd_raw(x, w, b, out_lrelu=True, want_bits=True)
+        src, xbits = ops.conv_fwd_raw(gy, w, None, flip=True, out_lrelu=True, want_bits=True)
+        dxm = ops.conv_fwd_raw(gy, w, None, flip=True, mask_bits=xbits)
+        dxf = ops.conv_fwd_raw(gy, w, None, flip=True, out_mask=x)
+        res[mode] = (y, ya, dxm, dxf, src)
+    for k in range(4):
+        a, r = res[5][k], res[0][k]
+        err = float((a - r).abs().max() / r.abs().max())
+        print("shape", B, Cin, Cout, sp, "output", k, "rel err", err)
+        assert err < 3e-5, (sp, k, err)
+    # the bit-masked result is the plain backward-data times the mask its own producer launch wrote
+    m = torch.where(res[5][4] > 0, 1.0, 0.2)
+    plain = ops.conv_fwd_raw(gy, w, None, flip=True)
+    lib.hpvg_conv_wino_config(5, -1)
+    plain5 = ops.conv_fwd_raw(gy, w, None, flip=True)
+    assert float((res[5][2] - plain5 * m).abs().max() / plain5.abs().max()) < 1e-6
+print("first generation ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPVG_WINO2R="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "first generation ok" in r.stdout, r.stdout + r.stderr
